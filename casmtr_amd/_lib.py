@@ -1,0 +1,76 @@
+"""ctypes binding of libcasmtr_hip.so (the C ABI declared in include/casmtr_hip.h).
+
+There is NO CPU fallback: if the library is missing or a kernel reports an error, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcasmtr_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+ERR_UNSUPPORTED = 1001
+
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): exactly the prototypes of include/casmtr_hip.h
+SIGNATURES = {
+    "casmtr_abi_version": (_I, []),
+    "casmtr_qta_score_fwd": (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    "casmtr_qta_score_bwd": (_I, [_P] * 6 + [_I] * 6 + [_P]),
+    "casmtr_qta_value_agg_fwd": (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    "casmtr_qta_value_agg_bwd": (_I, [_P] * 6 + [_I] * 6 + [_P]),
+    "casmtr_window_score_fwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "casmtr_window_score_bwd": (_I, [_P] * 6 + [_I] * 5 + [_P]),
+    "casmtr_nchw_to_tokens": (_I, [_P, _P, _I, _I, _I, _P]),
+    "casmtr_qta_coarse_level_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "casmtr_qta_coarse_level_ws_floats": (_SZ, [_I] * 4),
+    "casmtr_qta_fine_level_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "casmtr_cascade_attn_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P] + [_I] * 8 + [_P]),
+    "casmtr_window_warp_idx": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "casmtr_dual_softmax_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _I, _P, _I, _I, _I, _I, _I, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "casmtr_dual_softmax_ws_bytes": (_SZ, [_I] * 3),
+    "casmtr_window_match_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P] + [_I] * 7 + [_P]),
+    "casmtr_nms_select_fwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _I, _I, _F, _I, _P, _I, _P,
+                                   _P, _P, _P, _P, _P] + [_I] * 5 + [_P]),
+    "casmtr_nms_select_ws_bytes": (_SZ, [_I] * 3),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j4"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(casmtr_amd has no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI is incomplete
+            fn.restype, fn.argtypes = res, args
+        if l.casmtr_abi_version() != 1:
+            raise RuntimeError("libcasmtr_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code == ERR_UNSUPPORTED:
+        raise RuntimeError(f"{what}: shape not supported by the HIP kernel (CASMTR_ERR_UNSUPPORTED)")
+    raise RuntimeError(f"{what}: HIP error {code}")

@@ -1,0 +1,591 @@
+// Matching kernels for gfx950.
+//   casmtr_dual_softmax_fwd   CoarseMatching.forward + get_coarse_match    src/model/functions/coarse_matching.py:40-153
+//   casmtr_window_match_fwd   CascadeMatching.forward (one direction)      src/model/functions/cascade_matching.py:63-161
+//   casmtr_nms_select_fwd     CascadeMatching.get_coarse_match (inference) cascade_matching.py:170-261,317-331
+//                             + PostProcess.apply None/'maxpool_nms'       post_processing.py:41-44,111-121
+//                             + mask_window_border[_with_padding]          cascade_functions.py:120-172
+// Arithmetic for everything that feeds an index is the oracle's: operands pre-scaled by 1/sqrt(C) (division or
+// reciprocal multiply, `recip`), fp32 fmaf chain over c ascending (v_mfma_f32_32x32x2_f32 is exactly that chain),
+// result scaled by 1/T, masked entries = -1e9, argmax = first maximum of the LOGITS.
+#include "common.hpp"
+#include "../../include/casmtr_hip.h"
+
+using namespace casmtr;
+
+// =================================================================================================== dual softmax
+// Pass 1: sim = (f0/sqrtC) . (f1/sqrtC)^T / T on the fp32 matrix cores, 128x128 block tile, 4 waves x (64x64),
+// BK = 32.  The epilogue parks the tile in LDS, derives per-row / per-column (max, first argmax, sum exp) partials
+// for this block, and streams the tile to HBM (it is re-read once by pass 2; 468 MB/pair at 832x832 is cheaper
+// to move at 8 TB/s than to recompute at 157 TFLOP/s).
+#define DS_BM 128
+#define DS_BN 128
+#define DS_BK 32
+
+struct DsWs {  // carve of stats_ws
+    float *rp_m, *rp_s; int* rp_a;   // row partials  [B][NJB][L]
+    float *cp_m, *cp_s; int* cp_a;   // col partials  [B][NIB][S]
+    float *rmax, *rsum, *cmax, *csum;  // [B*L], [B*S]
+    unsigned long long *rbest, *cbest;  // packed (conf bits << 32 | ~idx)
+    unsigned char* flags;            // [B*L]
+    int64_t* jsel;                   // [B*L]
+    float* csel;                     // [B*L]
+    int* blk;                        // compaction block counts
+};
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+static size_t ds_carve(DsWs* w, char* base, int B, int L, int S) {
+    const size_t NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    size_t off = 0;
+#define CARVE(field, type, count)                                   \
+    do {                                                            \
+        if (w) w->field = reinterpret_cast<type*>(base + off);      \
+        off += align256(sizeof(type) * (size_t)(count));            \
+    } while (0)
+    CARVE(rp_m, float, (size_t)B * NJB * L); CARVE(rp_s, float, (size_t)B * NJB * L); CARVE(rp_a, int, (size_t)B * NJB * L);
+    CARVE(cp_m, float, (size_t)B * NIB * S); CARVE(cp_s, float, (size_t)B * NIB * S); CARVE(cp_a, int, (size_t)B * NIB * S);
+    CARVE(rmax, float, (size_t)B * L); CARVE(rsum, float, (size_t)B * L);
+    CARVE(cmax, float, (size_t)B * S); CARVE(csum, float, (size_t)B * S);
+    CARVE(rbest, unsigned long long, (size_t)B * L); CARVE(cbest, unsigned long long, (size_t)B * S);
+    CARVE(flags, unsigned char, (size_t)B * L); CARVE(jsel, int64_t, (size_t)B * L); CARVE(csel, float, (size_t)B * L);
+    CARVE(blk, int, ((size_t)B * L + 1023) / 1024 + 8);
+#undef CARVE
+    return off;
+}
+
+extern "C" size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S) { return ds_carve(nullptr, nullptr, B, L, S); }
+
+__global__ __launch_bounds__(256, 2) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                         const uint8_t* __restrict__ mask0,
+                                                         const uint8_t* __restrict__ mask1, float* __restrict__ sim,
+                                                         DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
+                                                         float T, float invT, int recip) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33]  then  tile[128][129]
+    float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
+    float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
+    float (*tile)[129] = reinterpret_cast<float (*)[129]>(smem);
+    const int b = blockIdx.z, i0 = blockIdx.y * DS_BM, j0 = blockIdx.x * DS_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = tid >> 1, lc0 = (tid & 1) * 16;
+    const float* ap = f0 + ((size_t)b * L + (i0 + lrow < L ? i0 + lrow : L - 1)) * C + lc0;
+    const float* bp = f1 + ((size_t)b * S + (j0 + lrow < S ? j0 + lrow : S - 1)) * C + lc0;
+    for (int k0 = 0; k0 < C; k0 += DS_BK) {
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * i);
+            bv[i] = *reinterpret_cast<const f32x4*>(bp + k0 + 4 * i);
+        }
+        __syncthreads();  // previous k-tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                As[lrow][lc0 + 4 * i + c] = div_scalar(av[i][c], sqrtC, inv_sqrtC, recip);
+                Bs[lrow][lc0 + 4 * i + c] = div_scalar(bv[i][c], sqrtC, inv_sqrtC, recip);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < DS_BK / 2; ++kk) {
+            const int kc = 2 * kk + (lane >> 5), rr = lane & 31;
+            const float a0 = As[wr * 64 + rr][kc], a1 = As[wr * 64 + 32 + rr][kc];
+            const float b0 = Bs[wc * 64 + rr][kc], b1 = Bs[wc * 64 + 32 + rr][kc];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // epilogue: scale, mask, park in LDS
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = wc * 64 + tj * 32 + (lane & 31);
+                float x = div_scalar(acc[ti][tj][r], T, invT, recip);
+                if (mask0) {
+                    const int gi = i0 + row, gj = j0 + col;
+                    const bool ok = gi < L && gj < S && mask0[(size_t)b * L + gi] && mask1[(size_t)b * S + gj];
+                    x = ok ? x : NEG_FILL;
+                }
+                tile[row][col] = x;
+            }
+    __syncthreads();
+    const int nr = min(DS_BM, L - i0), nc = min(DS_BN, S - j0);
+    const int NJB = gridDim.x, NIB = gridDim.y;
+    if (tid < 128) {
+        const int r = tid;
+        if (r < nr) {
+            float m = tile[r][0]; int am = 0;
+            for (int c = 1; c < nc; ++c) { const float x = tile[r][c]; if (x > m) { m = x; am = c; } }
+            float s = 0.f;
+            for (int c = 0; c < nc; ++c) s += expf(tile[r][c] - m);
+            const size_t o = ((size_t)b * NJB + blockIdx.x) * L + i0 + r;
+            w.rp_m[o] = m; w.rp_s[o] = s; w.rp_a[o] = j0 + am;
+        }
+    } else {
+        const int c = tid - 128;
+        if (c < nc) {
+            float m = tile[0][c]; int am = 0;
+            for (int r = 1; r < nr; ++r) { const float x = tile[r][c]; if (x > m) { m = x; am = r; } }
+            float s = 0.f;
+            for (int r = 0; r < nr; ++r) s += expf(tile[r][c] - m);
+            const size_t o = ((size_t)b * NIB + blockIdx.y) * S + j0 + c;
+            w.cp_m[o] = m; w.cp_s[o] = s; w.cp_a[o] = i0 + am;
+        }
+    }
+    // stream the tile out (row-major [B,L,S])
+    for (int e = tid; e < DS_BM * (DS_BN / 4); e += 256) {
+        const int r = e / (DS_BN / 4), c = (e % (DS_BN / 4)) * 4;
+        if (r >= nr || c >= nc) continue;
+        float* dst = sim + ((size_t)b * L + i0 + r) * S + j0 + c;
+        if ((S & 3) == 0 && c + 3 < nc) {
+            *reinterpret_cast<f32x4*>(dst) = (f32x4){tile[r][c], tile[r][c + 1], tile[r][c + 2], tile[r][c + 3]};
+        } else {
+            for (int u = 0; u < 4 && c + u < nc; ++u) dst[u] = tile[r][c + u];
+        }
+    }
+}
+
+// combine block partials -> per row/col (max, sum, first argmax); next_conf = softmax value at the argmax = 1/sum.
+__global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                        const int* __restrict__ pa, int nblk, int N, int total,
+                                                        float* __restrict__ omax, float* __restrict__ osum,
+                                                        int64_t* __restrict__ oidx, float* __restrict__ oconf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / N, i = t % N;
+    const size_t base = (size_t)b * nblk * N + i;
+    float m = pm[base]; int am = pa[base];
+    for (int k = 1; k < nblk; ++k) {
+        const float x = pm[base + (size_t)k * N];
+        if (x > m) { m = x; am = pa[base + (size_t)k * N]; }
+    }
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += ps[base + (size_t)k * N] * expf(pm[base + (size_t)k * N] - m);
+    omax[t] = m; osum[t] = s; oidx[t] = am; oconf[t] = 1.0f / s;
+}
+
+// Pass 2: conf = softmax10 * softmax01 (coarse_matching.py:66-68), best-of-row / best-of-column (value, first index)
+// through packed 64-bit atomicMax; optionally overwrites sim with conf (the reference's data['stage_8c']['conf_matrix']).
+__global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // tile[64][257], rm[64], rs[64]
+    float (*tile)[257] = reinterpret_cast<float (*)[257]>(smem);
+    float* rm = smem + 64 * 257;
+    float* rs = rm + 64;
+    const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 256;
+    const int tid = threadIdx.x;
+    const int nr = min(64, L - i0), nc = min(256, S - j0);
+    if (tid < 64 && tid < nr) {
+        rm[tid] = w.rmax[(size_t)b * L + i0 + tid];
+        rs[tid] = w.rsum[(size_t)b * L + i0 + tid];
+    }
+    __syncthreads();
+    if (tid < nc) {
+        const int gj = j0 + tid;
+        const float cm = w.cmax[(size_t)b * S + gj], cs = w.csum[(size_t)b * S + gj];
+        float best = -1.f; int bi = 0;
+        float* col = sim + ((size_t)b * L + i0) * S + gj;
+        for (int r = 0; r < nr; ++r) {
+            const float x = col[(size_t)r * S];
+            const float p01 = expf(x - rm[r]) / rs[r];
+            const float p10 = expf(x - cm) / cs;
+            const float cf = p10 * p01;
+            tile[r][tid] = cf;
+            if (want_conf) col[(size_t)r * S] = cf;
+            if (cf > best) { best = cf; bi = i0 + r; }
+        }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (0xFFFFFFFFu - (unsigned)bi);
+        atomicMax(w.cbest + (size_t)b * S + gj, key);
+    }
+    __syncthreads();
+    if (tid < nr) {
+        float best = -1.f; int bj = 0;
+        for (int c = 0; c < nc; ++c) { const float cf = tile[tid][c]; if (cf > best) { best = cf; bj = j0 + c; } }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (0xFFFFFFFFu - (unsigned)bj);
+        atomicMax(w.rbest + (size_t)b * L + i0 + tid, key);
+    }
+}
+
+// coarse_matching.py:116-132: conf > thr, border removal, mutual maximum BY VALUE, first j per row.
+__global__ __launch_bounds__(256) void ds_flag_kernel(DsWs w, float thr, int border_rm, const int32_t* __restrict__ valid_hw,
+                                                      int h0c, int w0c, int h1c, int w1c, int L, int S, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / L, i = t % L;
+    const unsigned long long key = w.rbest[t];
+    const float cf = __uint_as_float((unsigned)(key >> 32));
+    const int j = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+    bool ok = cf > thr;
+    if (ok) ok = (unsigned)(w.cbest[(size_t)b * S + j] >> 32) == (unsigned)(key >> 32);
+    if (ok && border_rm > 0) {
+        const int vh0 = valid_hw ? valid_hw[b * 4 + 0] : h0c, vw0 = valid_hw ? valid_hw[b * 4 + 1] : w0c;
+        const int vh1 = valid_hw ? valid_hw[b * 4 + 2] : h1c, vw1 = valid_hw ? valid_hw[b * 4 + 3] : w1c;
+        const int y0 = i / w0c, x0 = i % w0c, y1 = j / w1c, x1 = j % w1c;
+        if (y0 < border_rm || x0 < border_rm || y0 >= vh0 - border_rm || x0 >= vw0 - border_rm) ok = false;
+        if (y1 < border_rm || x1 < border_rm || y1 >= vh1 - border_rm || x1 >= vw1 - border_rm) ok = false;
+    }
+    w.flags[t] = ok ? 1 : 0;
+    w.jsel[t] = j;
+    w.csel[t] = cf;
+}
+
+// =================================================================================================== ordered compaction
+// flags[total] -> (b,i) ordered lists, as torch.where() would return them.  3 small kernels: per-1024 counts,
+// single-workgroup exclusive scan, ordered write.  `keep_one`: the reference's "mask[:, 0] = True" when nothing
+// survived in the whole batch (cascade_matching.py:254-255).
+__global__ __launch_bounds__(1024) void compact_count_kernel(const unsigned char* __restrict__ flags, int total,
+                                                             int* __restrict__ blk) {
+    __shared__ int wsum[16];
+    const int t = blockIdx.x * 1024 + threadIdx.x;
+    const bool f = t < total && flags[t];
+    const unsigned long long bal = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < 16; ++i) s += wsum[i];
+        blk[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int* __restrict__ blk, int nblk, int64_t* __restrict__ n_out,
+                                                            int keep_one, int B) {
+    // sequential chunks of 1024 blocks; nblk is a few hundred at most for this workload
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? blk[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblk) blk[i] = carry + part[threadIdx.x] - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        blk[nblk] = carry;  // total
+        *n_out = (carry == 0 && keep_one) ? B : carry;
+    }
+}
+
+__global__ __launch_bounds__(1024) void compact_write_kernel(const unsigned char* __restrict__ flags,
+                                                             const int64_t* __restrict__ jsrc,
+                                                             const float* __restrict__ csrc, const int* __restrict__ blk,
+                                                             int nblk, int total, int N, int keep_one,
+                                                             int64_t* __restrict__ b_ids, int64_t* __restrict__ i_ids,
+                                                             int64_t* __restrict__ j_ids, float* __restrict__ mconf) {
+    __shared__ int wsum[16];
+    const int t = blockIdx.x * 1024 + threadIdx.x;
+    if (blk[nblk] == 0) {
+        if (keep_one && t < total && (t % N) == 0) {
+            const int b = t / N;
+            b_ids[b] = b; i_ids[b] = 0; j_ids[b] = jsrc[t]; mconf[b] = csrc[t];
+        }
+        return;
+    }
+    const bool f = t < total && flags[t];
+    const unsigned long long bal = __ballot(f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int off = blk[blockIdx.x];
+    for (int i = 0; i < wv; ++i) off += wsum[i];
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    if (f) {
+        b_ids[off] = t / N; i_ids[off] = t % N; j_ids[off] = jsrc[t]; mconf[off] = csrc[t];
+    }
+}
+
+static int run_compaction(const unsigned char* flags, const int64_t* jsrc, const float* csrc, int* blk, int total, int N,
+                          int keep_one, int B, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf,
+                          int64_t* n_matches, hipStream_t s) {
+    const int nblk = (total + 1023) / 1024;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(1024), 0, s, flags, total, blk);
+    CASMTR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, blk, nblk, n_matches, keep_one, B);
+    CASMTR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_write_kernel, dim3(nblk), dim3(1024), 0, s, flags, jsrc, csrc, blk, nblk, total, N,
+                       keep_one, b_ids, i_ids, j_ids, mconf);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                                       float temperature, int recip, float thr, int border_rm, const int32_t* valid_hw,
+                                       int h0c, int w0c, int h1c, int w1c, int want_conf, float* sim_ws, void* stats_ws,
+                                       int64_t* next_idx01, float* next_conf01, int64_t* next_idx10, float* next_conf10,
+                                       int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches,
+                                       int B, int L, int S, int C, casmtr_stream_t stream) {
+    if (C % DS_BK != 0 || (mask0 == nullptr) != (mask1 == nullptr)) return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || L <= 0 || S <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    DsWs w;
+    ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S);
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    const float sqrtC = (float)sqrt((double)C);
+    static bool attr_set = false;
+    const size_t gemm_lds = sizeof(float) * 128 * 129, conf_lds = sizeof(float) * (64 * 257 + 128);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_conf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conf_lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ds_gemm_kernel, dim3(NJB, NIB, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws, w, L,
+                       S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, recip);
+    CASMTR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L,
+                       w.rmax, w.rsum, next_idx01, next_conf01);
+    CASMTR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, w.cp_a, NIB, S, B * S,
+                       w.cmax, w.csum, next_idx10, next_conf10);
+    CASMTR_CHECK_LAUNCH();
+    hipError_t e = hipMemsetAsync(w.rbest, 0, sizeof(unsigned long long) * (size_t)B * L, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(w.cbest, 0, sizeof(unsigned long long) * (size_t)B * S, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 255) / 256, (L + 63) / 64, B), dim3(256), conf_lds, s, sim_ws, w, L, S,
+                       want_conf);
+    CASMTR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ds_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, thr, border_rm, valid_hw, h0c, w0c,
+                       h1c, w1c, L, S, B * L);
+    CASMTR_CHECK_LAUNCH();
+    return run_compaction(w.flags, w.jsel, w.csel, w.blk, B * L, L, 0, B, b_ids, i_ids, j_ids, mconf, n_matches, s);
+}
+
+// =================================================================================================== window match
+// One workgroup per quad of query tokens (4 children of a coarse cell) when (h,w) is given: their K window rows are
+// the same list (CascadeQTAttB's upsampled_idx, modules/quadtree_attention.py:450), so the K x C key tile is
+// normalised and staged in LDS once and scored by 4 waves (wave <-> child token, lane <-> candidate).  If the 4 index
+// rows differ (generic caller) the tile is restaged per token -- same results, more traffic.
+template <int C>
+__global__ __launch_bounds__(256) void window_match_kernel(const float* __restrict__ fq, const float* __restrict__ fk,
+                                                           const int64_t* __restrict__ idx,
+                                                           const uint8_t* __restrict__ mq, const uint8_t* __restrict__ mk,
+                                                           float sqrtC, float inv_sqrtC, float T, float invT, int recip,
+                                                           float* __restrict__ conf, float* __restrict__ next_conf,
+                                                           int64_t* __restrict__ next_idx, int N, int M, int K, int h,
+                                                           int w) {
+    constexpr int CP = C + 4;   // padded row (floats): conflict-free ds_read_b128 across lanes
+    constexpr int KMAXW = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rows = smem;                                   // [KMAXW][CP]
+    int* cidx = reinterpret_cast<int*>(smem + KMAXW * CP);  // [4][KMAXW]
+    int& differ = cidx[4 * KMAXW];                          // all LDS in the dynamic region (keeps it 16-B aligned)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    int tok[4];
+    if (h > 0) {
+        const int wq = w >> 1, qy = blockIdx.x / wq, qx = blockIdx.x % wq;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) tok[f] = (2 * qy + (f >> 1)) * w + 2 * qx + (f & 1);
+    } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) tok[f] = blockIdx.x * 4 + f;
+    }
+    if (tid == 0) differ = 0;
+    __syncthreads();
+    for (int e = tid; e < 4 * K; e += 256) {
+        const int f = e / K, k = e % K;
+        cidx[f * KMAXW + k] = tok[f] < N ? (int)idx[((size_t)b * N + tok[f]) * K + k] : 0;
+    }
+    __syncthreads();
+    {
+        bool d = false;
+        for (int e = tid; e < 4 * K; e += 256) {
+            const int f = e / K, k = e % K;
+            if (tok[f] < N && cidx[f * KMAXW + k] != cidx[k]) d = true;
+        }
+        if (d) differ = 1;
+    }
+    __syncthreads();
+    const bool shared_rows = (differ == 0);
+    const int n = tok[wave];
+    const int rounds = shared_rows ? 1 : 4;
+    for (int rd = 0; rd < rounds; ++rd) {
+        if (rd > 0) __syncthreads();
+        {   // stage + normalise the K rows of token `rd`'s list (== everyone's list when shared)
+            const int c4 = (tid % (C / 4)) * 4;
+            for (int r = tid / (C / 4); r < K; r += 256 / (C / 4)) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(fk + ((size_t)b * M + cidx[rd * KMAXW + r]) * C + c4);
+                f32x4 o;
+                o.x = div_scalar(v.x, sqrtC, inv_sqrtC, recip); o.y = div_scalar(v.y, sqrtC, inv_sqrtC, recip);
+                o.z = div_scalar(v.z, sqrtC, inv_sqrtC, recip); o.w = div_scalar(v.w, sqrtC, inv_sqrtC, recip);
+                *reinterpret_cast<f32x4*>(rows + r * CP + c4) = o;
+            }
+        }
+        __syncthreads();
+        if ((shared_rows || wave == rd) && n < N) {
+            const float* qp = fq + ((size_t)b * N + n) * C;  // wave-uniform -> scalar loads
+            float qn[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) qn[c] = div_scalar(qp[c], sqrtC, inv_sqrtC, recip);
+            const int mqv = mq ? mq[(size_t)b * N + n] : 1;
+            float x[2];
+            unsigned key[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int k = p * 64 + lane;
+                x[p] = 0.f; key[p] = 0u;
+                if (k < K) {
+                    const f32x4* rp = reinterpret_cast<const f32x4*>(rows + k * CP);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < C / 4; ++i) {
+                        const f32x4 kv = rp[i];
+                        acc = __builtin_fmaf(qn[4 * i + 0], kv.x, acc);
+                        acc = __builtin_fmaf(qn[4 * i + 1], kv.y, acc);
+                        acc = __builtin_fmaf(qn[4 * i + 2], kv.z, acc);
+                        acc = __builtin_fmaf(qn[4 * i + 3], kv.w, acc);
+                    }
+                    float v = div_scalar(acc, T, invT, recip);
+                    if (mq && !(mqv && mk[(size_t)b * M + cidx[wave * KMAXW + k]])) v = NEG_FILL;
+                    x[p] = v; key[p] = f2ord(v);
+                }
+            }
+            const unsigned wm = wave_max_u32(max(key[0], key[1]));
+            const float m = ord2f(wm);
+            float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
+            float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
+            const float s = wave_sum_f32(e0 + e1);
+            e0 = e0 / s; e1 = e1 / s;
+            if (conf) {
+                if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
+                if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
+            }
+            const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
+            const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
+            const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+            if (lane == (am & 63)) {
+                next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
+                next_idx[(size_t)b * N + n] = cidx[wave * KMAXW + am];
+            }
+        }
+    }
+}
+
+template <int C>
+static int launch_window_match(const float* fq, const float* fk, const int64_t* idx, const uint8_t* mq, const uint8_t* mk,
+                               float T, int recip, float* conf, float* next_conf, int64_t* next_idx, int B, int N, int M,
+                               int K, int h, int w, hipStream_t s) {
+    const size_t lds = sizeof(float) * (128 * (C + 4) + 4 * 128 + 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_match_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const bool quad = h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N;
+    const float sqrtC = (float)sqrt((double)C);
+    const dim3 grid(quad ? (h / 2) * (w / 2) : (N + 3) / 4, B);
+    hipLaunchKernelGGL(window_match_kernel<C>, grid, dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC, 1.0f / sqrtC, T,
+                       1.0f / T, recip, conf, next_conf, next_idx, N, M, K, quad ? h : 0, quad ? w : 0);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int casmtr_window_match_fwd(const float* feat_q, const float* feat_k, const int64_t* idx, const uint8_t* mask_q,
+                                       const uint8_t* mask_k, float temperature, int recip, float* conf, float* next_conf,
+                                       int64_t* next_idx, int B, int N, int M, int K, int C, int h, int w,
+                                       casmtr_stream_t stream) {
+    if (K > 128 || K <= 0 || (mask_q == nullptr) != (mask_k == nullptr)) return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || N <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 128) return launch_window_match<128>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    if (C == 64) return launch_window_match<64>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    if (C == 32) return launch_window_match<32>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    return CASMTR_ERR_UNSUPPORTED;
+}
+
+// =================================================================================================== NMS + selection
+__global__ __launch_bounds__(256) void nms_flag_kernel(const float* __restrict__ conf, const int64_t* __restrict__ idx01,
+                                                       const int64_t* __restrict__ idx10, int nms_window, float test_thr,
+                                                       const float* __restrict__ pre0, int hp0, int wp0, float pt0,
+                                                       const float* __restrict__ pre1, int hp1, int wp1, float pt1,
+                                                       int border_rm, const int32_t* __restrict__ valid_hw,
+                                                       int double_check, unsigned char* __restrict__ keep, int B, int H0,
+                                                       int W0, int H1, int W1) {
+    const int N = H0 * W0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * N) return;
+    const int b = t / N, i = t % N, y = i / W0, x = i % W0;
+    const float* cf = conf + (size_t)b * N;
+    const float me = cf[i];
+    bool k = true;
+    if (nms_window > 0) {
+        // F.max_pool2d(return_indices=True): first maximum in row-major window scan wins (strict >), NaN propagates
+        const int r = nms_window / 2;
+        float best = 0.f; int bi = -1;
+        for (int yy = max(y - r, 0); yy <= min(y + r, H0 - 1); ++yy)
+            for (int xx = max(x - r, 0); xx <= min(x + r, W0 - 1); ++xx) {
+                const float v = cf[yy * W0 + xx];
+                if (bi < 0 || v > best || v != v) { best = v; bi = yy * W0 + xx; }
+            }
+        k = (bi == i);
+    }
+    if (!(me > test_thr)) k = false;
+    if (pre0) {
+        int sy = (int)floorf((float)y * ((float)hp0 / (float)H0)); sy = min(sy, hp0 - 1);
+        int sx = (int)floorf((float)x * ((float)wp0 / (float)W0)); sx = min(sx, wp0 - 1);
+        if (pre0[(size_t)b * hp0 * wp0 + sy * wp0 + sx] <= pt0) k = false;
+    }
+    if (pre1) {
+        int sy = (int)floorf((float)y * ((float)hp1 / (float)H0)); sy = min(sy, hp1 - 1);
+        int sx = (int)floorf((float)x * ((float)wp1 / (float)W0)); sx = min(sx, wp1 - 1);
+        if (pre1[(size_t)b * hp1 * wp1 + sy * wp1 + sx] <= pt1) k = false;
+    }
+    const int64_t j = idx01[t];
+    if (border_rm > 0) {
+        const int vh0 = valid_hw ? valid_hw[b * 4 + 0] : H0, vw0 = valid_hw ? valid_hw[b * 4 + 1] : W0;
+        const int vh1 = valid_hw ? valid_hw[b * 4 + 2] : H1, vw1 = valid_hw ? valid_hw[b * 4 + 3] : W1;
+        if (y < border_rm || x < border_rm || y >= vh0 - border_rm || x >= vw0 - border_rm) k = false;
+        const int ty = (int)(j / W1), tx = (int)(j % W1);
+        if (tx < border_rm || tx > vw1 - border_rm || ty < border_rm || ty > vh1 - border_rm) k = false;  // :137-138
+    }
+    if (double_check && idx10[(size_t)b * H1 * W1 + j] != i) k = false;
+    keep[t] = k ? 1 : 0;
+}
+
+extern "C" size_t casmtr_nms_select_ws_bytes(int B, int H0, int W0) {
+    const size_t total = (size_t)B * H0 * W0;
+    return align256(total) + align256(sizeof(int) * ((total + 1023) / 1024 + 8));
+}
+
+extern "C" int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* next_idx01, const int64_t* next_idx10,
+                                     int nms_window, float test_thr, const float* pre_conf0, int hp0, int wp0,
+                                     float pre_thr0, const float* pre_conf1, int hp1, int wp1, float pre_thr1,
+                                     int border_rm, const int32_t* valid_hw, int double_check, void* ws, int64_t* b_ids,
+                                     int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches, int B, int H0,
+                                     int W0, int H1, int W1, casmtr_stream_t stream) {
+    if (B <= 0 || H0 <= 0 || W0 <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int total = B * H0 * W0;
+    unsigned char* keep = reinterpret_cast<unsigned char*>(ws);
+    int* blk = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align256((size_t)total));
+    hipLaunchKernelGGL(nms_flag_kernel, dim3((total + 255) / 256), dim3(256), 0, s, next_conf01, next_idx01, next_idx10,
+                       nms_window, test_thr, pre_conf0, hp0, wp0, pre_thr0, pre_conf1, hp1, wp1, pre_thr1, border_rm,
+                       valid_hw, double_check, keep, B, H0, W0, H1, W1);
+    CASMTR_CHECK_LAUNCH();
+    return run_compaction(keep, next_idx01, next_conf01, blk, total, H0 * W0, 1, B, b_ids, i_ids, j_ids, mconf, n_matches, s);
+}

@@ -1,0 +1,542 @@
+// Fused QuadTreeAttention kernels for gfx950 (wave64).
+//   quad_attn_kernel<H,KMAX,0>  QTAttB.process_fine_level + merge share   modules/quadtree_attention.py:180-229,262-284
+//   quad_attn_kernel<H,KMAX,1>  CascadeQTAttB.forward                     modules/quadtree_attention.py:400-452
+//   coarse_*                    QTAttB.process_coarse_level               modules/quadtree_attention.py:161-178
+// One workgroup per quad (parent token): the 4 children share the candidate list, so every gathered key / value
+// row is fetched once per quad.  Nothing between the gather and the message ever goes to HBM: the reference's
+// [B,L/4,4,K,H] score / softmax / int64 index intermediates (:206-223) live in LDS and registers.
+// Arithmetic for anything that feeds an index: fp32 fmaf chain over d ascending, logits = fl(temp*dot), selection
+// on logits ordered (logit desc, position asc) -- identical to oracle/casmtr_oracle.c.
+#include "common.hpp"
+#include "../../include/casmtr_hip.h"
+
+using namespace casmtr;
+
+// =================================================================================================== layout
+// [B,C,HW] -> [B,HW,C], 32x32 LDS tile, both sides coalesced.
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
+                                                             int HW) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, p = p0 + tx;
+        if (c < C && p < HW) t[ty + 8 * i][tx] = x[((size_t)b * C + c) * HW + p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i, c = c0 + tx;
+        if (c < C && p < HW) out[((size_t)b * HW + p) * C + c] = t[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int casmtr_nchw_to_tokens(const float* x, float* out, int B, int C, int HW, casmtr_stream_t stream) {
+    if (B <= 0 || C <= 0 || HW <= 0) return 0;
+    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                       (hipStream_t)stream, x, out, C, HW);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================== quad kernel
+struct QuadArgs {
+    const float* q;        // [B,L,H*32]
+    const float* key;      // [B,S,H*32]
+    const float* value;    // [B,S,H*32]
+    const int64_t* pidx;   // MODE 0: prev_idx [B,Lq,Kp,H] ; MODE 1: topk_pos [B,Lq,KW,2]
+    const float* rel_pos;  // MODE 1 only, nullable [B,H,L,K]
+    const float* acc_in;   // MODE 0, nullable [B,Lq,H*32]
+    float* message;        // nullable [B,L,H*32]
+    float* acc_out;        // nullable [B,L,H*32]
+    float* topk_score;     // [B,L,topk,H]
+    int64_t* topk_idx;     // [B,L,topk,H]
+    int64_t* up_idx;       // MODE 1, nullable [B,L,K]
+    float temp, w_level;
+    int topk, dilated;
+    int h0, w0, h1, w1, Kp;  // Kp = parent entries per quad (K = 4*Kp)
+};
+
+template <int H, int KMAX, int MODE>
+__global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
+    constexpr int HD = H * 32;
+    constexpr int PPH = KMAX / 64;    // 64-candidate passes per head
+    constexpr int E = KMAX / 16;      // elements per lane in the 16-lane-row softmax / top-k
+    constexpr int NSL = 256 / (H * 8);  // candidate slices in the aggregation phase
+    constexpr int CANDN = MODE == 0 ? H * KMAX : KMAX;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* cand = reinterpret_cast<int*>(smem);          // [H][KMAX] (MODE 0) or [KMAX]
+    float* Sld = smem + CANDN;                         // [4][H][KMAX] logits
+    float* Ald = Sld + 4 * H * KMAX;                   // [H][KMAX][4] probabilities
+    float* red = Ald + 4 * H * KMAX;                   // [NSL][4][H*8] float4 partial sums (= 4096 floats)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, n = blockIdx.x;
+    const int wq = a.w0 >> 1, Lq = (a.h0 >> 1) * wq, L = a.h0 * a.w0, S = a.h1 * a.w1;
+    const int K = 4 * a.Kp;
+    const int qy = n / wq, qx = n % wq;
+    const int l00 = (2 * qy) * a.w0 + 2 * qx;  // child f -> l00 + (f>>1)*w0 + (f&1)
+
+    // ---- phase 0: candidate list
+    if (MODE == 0) {
+        const int w1p = a.w1 >> 1;
+        for (int e = tid; e < a.Kp * H; e += 256) {
+            const int kp = e / H, h = e % H;
+            const int64_t p = a.pidx[(((size_t)b * Lq + n) * a.Kp + kp) * H + h];
+            const int r = (int)(p / w1p) * 2, c = (int)(p % w1p) * 2;
+            int* cp = cand + h * KMAX + kp * 4;
+            cp[0] = r * a.w1 + c;
+            cp[1] = r * a.w1 + c + 1;
+            cp[2] = (r + 1) * a.w1 + c;
+            cp[3] = (r + 1) * a.w1 + c + 1;
+        }
+    } else {
+        for (int e = tid; e < a.Kp; e += 256) {
+            const int64_t r = a.pidx[(((size_t)b * Lq + n) * a.Kp + e) * 2 + 0] * 2;
+            const int64_t c = a.pidx[(((size_t)b * Lq + n) * a.Kp + e) * 2 + 1] * 2;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int64_t id = (r + (t >> 1) * a.dilated) * a.w1 + c + (t & 1) * a.dilated;
+                id = id < 0 ? 0 : (id > (int64_t)S - 1 ? (int64_t)S - 1 : id);  // torch.clamp, :429
+                cand[e * 4 + t] = (int)id;
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE == 1 && a.up_idx) {
+        for (int e = tid; e < 4 * K; e += 256) {
+            const int f = e / K, k = e % K;
+            a.up_idx[((size_t)b * L + l00 + (f >> 1) * a.w0 + (f & 1)) * K + k] = cand[k];
+        }
+    }
+
+    // ---- phase 1: logits.  wave <-> (head, 64-candidate pass); lane <-> candidate; query rows through scalar loads.
+    for (int p = wave; p < H * PPH; p += 4) {
+        const int h = p / PPH;
+        const int k = (p % PPH) * 64 + lane;
+        const bool valid = k < K;
+        const int row = cand[(MODE == 0 ? h * KMAX : 0) + (valid ? k : 0)];
+        const f32x4* kp = reinterpret_cast<const f32x4*>(a.key + ((size_t)b * S + row) * HD + h * 32);
+        f32x4 kr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kr[i] = kp[i];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
+            const float* qp = a.q + ((size_t)b * L + lf) * HD + h * 32;  // wave-uniform -> s_load
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc = __builtin_fmaf(qp[4 * i + 0], kr[i].x, acc);
+                acc = __builtin_fmaf(qp[4 * i + 1], kr[i].y, acc);
+                acc = __builtin_fmaf(qp[4 * i + 2], kr[i].z, acc);
+                acc = __builtin_fmaf(qp[4 * i + 3], kr[i].w, acc);
+            }
+            float lg = a.temp * acc;
+            if (MODE == 1 && a.rel_pos && valid) lg = lg + a.rel_pos[(((size_t)b * H + h) * L + lf) * K + k];
+            Sld[(f * H + h) * KMAX + k] = lg;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax (+ top-k) per series (child f, head h); one series per 16-lane DPP row, 4 per wave pass.
+    {
+        const int rowi = lane >> 4, j = lane & 15;
+        for (int g = wave; g < (4 * H + 3) / 4; g += 4) {
+            const int sid = g * 4 + rowi;
+            const bool svalid = sid < 4 * H;
+            const int f = svalid ? sid / H : 0, h = svalid ? sid % H : 0;
+            float lv[E];
+            unsigned key[E];
+            const f32x4* sp = reinterpret_cast<const f32x4*>(Sld + (f * H + h) * KMAX + j * E);
+#pragma unroll
+            for (int e4 = 0; e4 < E / 4; ++e4) {
+                const f32x4 v = sp[e4];
+                lv[4 * e4 + 0] = v.x; lv[4 * e4 + 1] = v.y; lv[4 * e4 + 2] = v.z; lv[4 * e4 + 3] = v.w;
+            }
+            unsigned lm = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                key[e] = (j * E + e < K) ? f2ord(lv[e]) : 0u;
+                lm = max(lm, key[e]);
+            }
+            const float m = ord2f(row16_max_u32(lm));
+            float ps[E];
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ps[e] = (j * E + e < K) ? expf(lv[e] - m) : 0.f;
+                s += ps[e];
+            }
+            s = row16_sum_f32(s);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ps[e] = ps[e] / s;
+                Ald[(h * KMAX + j * E + e) * 4 + f] = ps[e];
+            }
+            if (MODE == 0) {
+                const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
+                for (int t = 0; t < a.topk; ++t) {
+                    unsigned cur = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) cur = max(cur, key[e]);
+                    const unsigned rm = row16_max_u32(cur);
+                    const unsigned long long bal = __ballot(cur == rm);
+                    const unsigned bits = (unsigned)(bal >> (rowi * 16)) & 0xFFFFu;
+                    const int wj = __ffs(bits) - 1;  // first lane of the row holding the maximum -> smallest position
+                    if (j == wj) {
+                        bool done = false;
+                        int kpos = 0;
+                        float sc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const bool hit = !done && key[e] == rm;
+                            if (hit) { kpos = j * E + e; sc = ps[e]; key[e] = 0u; done = true; }
+                        }
+                        if (svalid) {
+                            const size_t o = (((size_t)b * L + lf) * a.topk + t) * H + h;
+                            a.topk_idx[o] = cand[h * KMAX + kpos];
+                            a.topk_score[o] = sc;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: message = A . V ; thread <-> (candidate slice, head, float4 of D), 4 children accumulated together.
+    {
+        const int s = tid / (H * 8), item = tid % (H * 8), h = item >> 3, dq = item & 7;
+        f32x4 acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int* cp = cand + (MODE == 0 ? h * KMAX : 0);
+        const float* vb = a.value + (size_t)b * S * HD + h * 32 + dq * 4;
+#pragma unroll 4
+        for (int k = s; k < K; k += NSL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vb + (size_t)cp[k] * HD);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ald + (h * KMAX + k) * 4);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                acc[f].x = __builtin_fmaf(a4[f], v.x, acc[f].x);
+                acc[f].y = __builtin_fmaf(a4[f], v.y, acc[f].y);
+                acc[f].z = __builtin_fmaf(a4[f], v.z, acc[f].z);
+                acc[f].w = __builtin_fmaf(a4[f], v.w, acc[f].w);
+            }
+        }
+        f32x4* r4 = reinterpret_cast<f32x4*>(red);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) r4[(s * 4 + f) * (H * 8) + item] = acc[f];
+        __syncthreads();
+        if (tid < 4 * H * 8) {
+            const int f = tid / (H * 8), it = tid % (H * 8);
+            f32x4 tot = r4[f * (H * 8) + it];
+#pragma unroll
+            for (int ss = 1; ss < NSL; ++ss) {
+                const f32x4 p = r4[(ss * 4 + f) * (H * 8) + it];
+                tot.x += p.x; tot.y += p.y; tot.z += p.z; tot.w += p.w;
+            }
+            const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
+            const size_t o = ((size_t)b * L + lf) * HD + it * 4;
+            if (a.message) *reinterpret_cast<f32x4*>(a.message + o) = tot;
+            if (a.acc_out) {
+                f32x4 base = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.acc_in) base = *reinterpret_cast<const f32x4*>(a.acc_in + ((size_t)b * Lq + n) * HD + it * 4);
+                f32x4 r;  // final = final[parent] + m * weight   (:277-281): separate multiply and add
+                r.x = base.x + tot.x * a.w_level; r.y = base.y + tot.y * a.w_level;
+                r.z = base.z + tot.z * a.w_level; r.w = base.w + tot.w * a.w_level;
+                *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
+            }
+        }
+    }
+}
+
+template <int H, int KMAX, int MODE>
+static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
+    constexpr int CANDN = MODE == 0 ? H * KMAX : KMAX;
+    const size_t lds = sizeof(float) * (CANDN + 8 * H * KMAX + 4096);
+    const int Lq = (a.h0 / 2) * (a.w0 / 2);
+    static bool attr_set = false;  // one process per GPU: no cross-device state to worry about
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quad_attn_kernel<H, KMAX, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq, B), dim3(256), lds, s, a);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int MODE>
+static int dispatch_quad(const QuadArgs& a, int B, int H, hipStream_t s) {
+    const int K = 4 * a.Kp;
+#define QUAD_CASE(HH)                                                    \
+    if (H == HH) {                                                       \
+        if (K <= 64) return launch_quad<HH, 64, MODE>(a, B, s);          \
+        if (K <= 128) return launch_quad<HH, 128, MODE>(a, B, s);        \
+        if (K <= 256) return launch_quad<HH, 256, MODE>(a, B, s);        \
+        return CASMTR_ERR_UNSUPPORTED;                                   \
+    }
+    QUAD_CASE(8)
+    QUAD_CASE(4)
+    QUAD_CASE(2)
+#undef QUAD_CASE
+    return CASMTR_ERR_UNSUPPORTED;
+}
+
+extern "C" int casmtr_qta_fine_level_fwd(const float* q, const float* key, const float* value, const int64_t* prev_idx,
+                                         float temp, int topk, float w_level, const float* acc_in, float* message,
+                                         float* acc_out, float* topk_score, int64_t* topk_idx, int B, int h0, int w0,
+                                         int h1, int w1, int H, int D, int Kp, casmtr_stream_t stream) {
+    if (D != 32 || (h0 & 1) || (w0 & 1) || (h1 & 1) || (w1 & 1) || topk > 4 * Kp) return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
+    QuadArgs a{};
+    a.q = q; a.key = key; a.value = value; a.pidx = prev_idx; a.rel_pos = nullptr; a.acc_in = acc_in;
+    a.message = message; a.acc_out = acc_out; a.topk_score = topk_score; a.topk_idx = topk_idx; a.up_idx = nullptr;
+    a.temp = temp; a.w_level = w_level; a.topk = topk; a.dilated = 1;
+    a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.Kp = Kp;
+    return dispatch_quad<0>(a, B, H, (hipStream_t)stream);
+}
+
+extern "C" int casmtr_cascade_attn_fwd(const float* q, const float* key, const float* value, const int64_t* topk_pos,
+                                       const float* rel_pos, float temp, int dilated, float* message, int64_t* up_idx,
+                                       int B, int h0, int w0, int h1, int w1, int nhead, int D, int KW,
+                                       casmtr_stream_t stream) {
+    if (D != 32 || (h0 & 1) || (w0 & 1)) return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
+    QuadArgs a{};
+    a.q = q; a.key = key; a.value = value; a.pidx = topk_pos; a.rel_pos = rel_pos; a.acc_in = nullptr;
+    a.message = message; a.acc_out = nullptr; a.topk_score = nullptr; a.topk_idx = nullptr; a.up_idx = up_idx;
+    a.temp = temp; a.w_level = 1.f; a.topk = 0; a.dilated = dilated;
+    a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.Kp = KW;
+    return dispatch_quad<1>(a, B, nhead, (hipStream_t)stream);
+}
+
+// =================================================================================================== coarsest level
+// (1) logits[bh][l][s] = temp * <q[l,h,:], k[s,h,:]> on the fp32 matrix cores.  v_mfma_f32_32x32x2_f32 is an exact
+//     k-ordered fmaf chain (MI355X guide), so the result is bit-identical to the oracle's sequential chain.
+__global__ __launch_bounds__(256) void coarse_logits_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            float* __restrict__ Sg, float temp, int L, int S, int Spad,
+                                                            int H) {
+    __shared__ float Qs[64][33];
+    __shared__ float Ks[64][33];
+    const int bh = blockIdx.z, b = bh / H, h = bh % H;
+    const int l0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const int row = tid >> 2, c0 = (tid & 3) * 8;
+        const int l = l0 + row, s = s0 + row;
+        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f}, q0 = z, q1 = z, k0 = z, k1 = z;
+        if (l < L) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(q + (((size_t)b * L + l) * H + h) * 32 + c0);
+            q0 = p[0]; q1 = p[1];
+        }
+        if (s < S) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(k + (((size_t)b * S + s) * H + h) * 32 + c0);
+            k0 = p[0]; k1 = p[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Qs[row][c0 + i] = q0[i]; Qs[row][c0 + 4 + i] = q1[i];
+            Ks[row][c0 + i] = k0[i]; Ks[row][c0 + 4 + i] = k1[i];
+        }
+    }
+    __syncthreads();
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const float av = Qs[wr * 32 + (lane & 31)][2 * kk + (lane >> 5)];
+        const float bv = Ks[wc * 32 + (lane & 31)][2 * kk + (lane >> 5)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    const int s = s0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int l = l0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (l < L) Sg[((size_t)bh * L + l) * Spad + s] = temp * acc[r];
+    }
+}
+
+// (2) one wave per (b,h,l) row: softmax over S (probabilities written back in place), top-k by iterative wave argmax.
+template <int EMAX>
+__global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg, float* __restrict__ topk_score,
+                                                         int64_t* __restrict__ topk_idx, int topk, int B, int L, int S,
+                                                         int Spad, int H) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rowid = blockIdx.x * 4 + wave;
+    if (rowid >= B * H * L) return;
+    const int bh = rowid / L, l = rowid % L, b = bh / H, h = bh % H;
+    float* row = Sg + (size_t)rowid * Spad;
+    float lv[EMAX];
+    unsigned key[EMAX];
+    unsigned lm = 0;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int kx = e * 64 + lane;
+        lv[e] = (kx < S) ? row[kx] : 0.f;
+        key[e] = (kx < S) ? f2ord(lv[e]) : 0u;
+        lm = max(lm, key[e]);
+    }
+    const float m = ord2f(wave_max_u32(lm));
+    float ps[EMAX];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        ps[e] = (e * 64 + lane < S) ? expf(lv[e] - m) : 0.f;
+        s += ps[e];
+    }
+    s = wave_sum_f32(s);
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        ps[e] = ps[e] / s;
+        if (e * 64 + lane < Spad) row[e * 64 + lane] = ps[e];  // zero in the [S,Spad) padding
+    }
+    for (int t = 0; t < topk; ++t) {
+        unsigned cur = 0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) cur = max(cur, key[e]);
+        const unsigned wm = wave_max_u32(cur);
+        bool found = false;  // wave-uniform
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if (!found) {
+                const unsigned long long bal = __ballot(key[e] == wm);
+                if (bal) {
+                    found = true;
+                    const int src = __ffsll((long long)bal) - 1;  // smallest lane at the smallest e -> smallest position
+                    if (lane == src) {
+                        const size_t o = (((size_t)b * L + l) * topk + t) * H + h;
+                        topk_idx[o] = e * 64 + src;
+                        topk_score[o] = ps[e];
+                        key[e] = 0u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// (3) message[b,l,h,:] = sum_s P[bh][l][s] * v[b,s,h,:] on the fp32 matrix cores (s ascending chain).
+__global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict__ Pg, const float* __restrict__ v,
+                                                        float* __restrict__ message, float* __restrict__ acc_out,
+                                                        float w_level, int L, int S, int Spad, int H) {
+    __shared__ float Ps[128][33];
+    __shared__ float Vs[32][33];
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int l0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s0 = 0; s0 < Spad; s0 += 32) {
+        __syncthreads();
+        {   // P chunk: 128 rows x 32 cols ; thread -> (row = tid>>1, 16 cols)
+            const int row = tid >> 1, c0 = (tid & 1) * 16;
+            const int l = l0 + row;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (l < L) p = *reinterpret_cast<const f32x4*>(Pg + ((size_t)bh * L + l) * Spad + s0 + c0 + 4 * i);
+                Ps[row][c0 + 4 * i + 0] = p.x; Ps[row][c0 + 4 * i + 1] = p.y;
+                Ps[row][c0 + 4 * i + 2] = p.z; Ps[row][c0 + 4 * i + 3] = p.w;
+            }
+            // V chunk: 32 rows x 32 cols ; thread -> (row = tid>>3, 4 cols)
+            const int vr = tid >> 3, vc = (tid & 7) * 4;
+            f32x4 vv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (s0 + vr < S) vv = *reinterpret_cast<const f32x4*>(v + (((size_t)b * S + s0 + vr) * H + h) * 32 + vc);
+            Vs[vr][vc + 0] = vv.x; Vs[vr][vc + 1] = vv.y; Vs[vr][vc + 2] = vv.z; Vs[vr][vc + 3] = vv.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float av = Ps[wave * 32 + (lane & 31)][2 * kk + (lane >> 5)];
+            const float bv = Vs[2 * kk + (lane >> 5)][lane & 31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    const int d = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int l = l0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (l < L) {
+            const size_t o = (((size_t)b * L + l) * H + h) * 32 + d;
+            if (message) message[o] = acc[r];
+            if (acc_out) acc_out[o] = acc[r] * w_level;  // final_message = m * weight[0]  (:274)
+        }
+    }
+}
+
+extern "C" size_t casmtr_qta_coarse_level_ws_floats(int B, int L, int S, int H) {
+    const size_t Spad = ((size_t)S + 63) / 64 * 64;
+    return (size_t)B * H * L * Spad;
+}
+
+extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const float* v, float temp, int topk,
+                                           float w_level, float* logits_ws, float* message, float* acc_out,
+                                           float* topk_score, int64_t* topk_idx, int B, int L, int S, int H, int D,
+                                           casmtr_stream_t stream) {
+    if (D != 32 || topk > S) return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || L <= 0 || S <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int Spad = (S + 63) / 64 * 64;
+    hipLaunchKernelGGL(coarse_logits_kernel, dim3(Spad / 64, (L + 63) / 64, B * H), dim3(256), 0, s, q, k, logits_ws,
+                       temp, L, S, Spad, H);
+    CASMTR_CHECK_LAUNCH();
+    const int rows = B * H * L;
+    const dim3 rg((rows + 3) / 4);
+    const int E = Spad / 64;
+    if (E <= 4)
+        hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+    else if (E <= 8)
+        hipLaunchKernelGGL(coarse_row_kernel<8>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+    else if (E <= 12)
+        hipLaunchKernelGGL(coarse_row_kernel<12>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+    else if (E <= 16)
+        hipLaunchKernelGGL(coarse_row_kernel<16>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+    else if (E <= 32)
+        hipLaunchKernelGGL(coarse_row_kernel<32>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+    else
+        return CASMTR_ERR_UNSUPPORTED;
+    CASMTR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(coarse_av_kernel, dim3((L + 127) / 128, B * H), dim3(256), 0, s, logits_ws, v, message, acc_out,
+                       w_level, L, S, Spad, H);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================== window generator
+__global__ __launch_bounds__(256) void window_warp_idx_kernel(const int64_t* __restrict__ idx, int64_t* __restrict__ out,
+                                                              long long total, int H, int W, int ws) {
+    const int r = ws / 2, ww = ws * ws;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total * ww;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long tok = t / ww;
+        const int e = (int)(t % ww);
+        const long long y = idx[tok] / W, x = idx[tok] % W;
+        const long long uy = y - r < 0 ? y - r : 0, ux = x - r < 0 ? x - r : 0;
+        const long long oy = y + r >= H ? y + r - (H - 1) : 0, ox = x + r >= W ? x + r - (W - 1) : 0;
+        out[t * 2 + 0] = y + (e / ws - r) - uy - oy;
+        out[t * 2 + 1] = x + (e % ws - r) - ux - ox;
+    }
+}
+
+extern "C" int casmtr_window_warp_idx(const int64_t* idx, int64_t* out, int B, int N, int H, int W, int ws,
+                                      casmtr_stream_t stream) {
+    const long long total = (long long)B * N;
+    if (total <= 0) return 0;
+    long long blocks = (total * ws * ws + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(window_warp_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, out, total,
+                       H, W, ws);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int casmtr_abi_version(void) { return CASMTR_ABI_VERSION; }

@@ -1,0 +1,256 @@
+"""Tensor-level front end of the C ABI: argument checks, output allocation, current HIP stream + device guard.
+
+PyTorch is plumbing here (device memory, streams); every computation below is a hand-written gfx950 kernel in
+libcasmtr_hip.so.  The preconditions mirror the reference's TORCH_CHECKs (score_computation.cpp:6-8): tensors must
+be device-resident and contiguous, fp32 values, int64 indices -- violations raise RuntimeError, nothing falls back
+to the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (HIP) tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _u8(mask):
+    """bool / uint8 mask -> contiguous uint8 (same bytes; no copy for contiguous bool tensors)."""
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        mask = mask.contiguous().view(torch.uint8)
+    return _chk(mask.contiguous(), "mask", torch.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in primitives
+def qta_score_fwd(query, key, index):
+    _chk(query, "query"), _chk(key, "key"), _chk(index, "index", torch.int64)
+    B, N1, four, H, D = query.shape
+    assert four == 4
+    N2, K = key.shape[1], index.shape[2]
+    out = torch.empty((B, N1, 4, K, H), device=query.device, dtype=torch.float32)
+    with torch.cuda.device(query.device):
+        _lib.check(_lib.lib().casmtr_qta_score_fwd(_ptr(query), _ptr(key), _ptr(index), _ptr(out), B, N1, N2, K, H, D,
+                                                    _stream()), "qta_score_fwd")
+    return out
+
+
+def qta_score_bwd(grad, query, key, index):
+    _chk(grad, "grad"), _chk(query, "query"), _chk(key, "key"), _chk(index, "index", torch.int64)
+    B, N1, _, H, D = query.shape
+    N2, K = key.shape[1], index.shape[2]
+    dq, dk = torch.empty_like(query), torch.empty_like(key)
+    with torch.cuda.device(query.device):
+        _lib.check(_lib.lib().casmtr_qta_score_bwd(_ptr(grad), _ptr(query), _ptr(key), _ptr(index), _ptr(dq), _ptr(dk),
+                                                    B, N1, N2, K, H, D, _stream()), "qta_score_bwd")
+    return dq, dk
+
+
+def qta_value_agg_fwd(score, value, index, output):
+    _chk(score, "score"), _chk(value, "value"), _chk(index, "index", torch.int64), _chk(output, "output")
+    B, N, K, H = score.shape
+    M, D = value.shape[1], value.shape[3]
+    with torch.cuda.device(score.device):
+        _lib.check(_lib.lib().casmtr_qta_value_agg_fwd(_ptr(score), _ptr(value), _ptr(index), _ptr(output), B, N, K, H,
+                                                        M, D, _stream()), "qta_value_agg_fwd")
+
+
+def qta_value_agg_bwd(grad_out, score, value, index, grad_score, grad_value):
+    for t, n in ((grad_out, "grad_out"), (score, "score"), (value, "value"), (grad_score, "grad_score"),
+                 (grad_value, "grad_value")):
+        _chk(t, n)
+    _chk(index, "index", torch.int64)
+    B, N, K, H = score.shape
+    M, D = value.shape[1], value.shape[3]
+    with torch.cuda.device(score.device):
+        _lib.check(_lib.lib().casmtr_qta_value_agg_bwd(_ptr(grad_out), _ptr(score), _ptr(value), _ptr(index),
+                                                        _ptr(grad_score), _ptr(grad_value), B, N, K, H, M, D, _stream()),
+                   "qta_value_agg_bwd")
+
+
+def window_score_fwd(query, key, index):
+    _chk(query, "query"), _chk(key, "key"), _chk(index, "index", torch.int64)
+    B, N1, Cc = query.shape
+    N2, K = key.shape[1], index.shape[2]
+    out = torch.empty((B, N1, K), device=query.device, dtype=torch.float32)
+    with torch.cuda.device(query.device):
+        _lib.check(_lib.lib().casmtr_window_score_fwd(_ptr(query), _ptr(key), _ptr(index), _ptr(out), B, N1, N2, K, Cc,
+                                                       _stream()), "window_score_fwd")
+    return out
+
+
+def window_score_bwd(grad, query, key, index):
+    _chk(grad, "grad"), _chk(query, "query"), _chk(key, "key"), _chk(index, "index", torch.int64)
+    B, N1, Cc = query.shape
+    N2, K = key.shape[1], index.shape[2]
+    dq, dk = torch.empty_like(query), torch.empty_like(key)
+    with torch.cuda.device(query.device):
+        _lib.check(_lib.lib().casmtr_window_score_bwd(_ptr(grad), _ptr(query), _ptr(key), _ptr(index), _ptr(dq),
+                                                       _ptr(dk), B, N1, N2, K, Cc, _stream()), "window_score_bwd")
+    return dq, dk
+
+
+# ------------------------------------------------------------------------------------------------ fused kernels
+def nchw_to_tokens(x):
+    """[B,C,h,w] -> [B,h*w,C]"""
+    _chk(x, "x")
+    B, Cc, h, w = x.shape
+    out = torch.empty((B, h * w, Cc), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().casmtr_nchw_to_tokens(_ptr(x), _ptr(out), B, Cc, h * w, _stream()), "nchw_to_tokens")
+    return out
+
+
+def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
+    """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
+    _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
+    B, L, Cc = q.shape
+    S, D = k.shape[1], Cc // nhead
+    l = _lib.lib()
+    ws = torch.empty(l.casmtr_qta_coarse_level_ws_floats(B, L, S, nhead), device=q.device, dtype=torch.float32)
+    msg = torch.empty((B, L, nhead, D), device=q.device, dtype=torch.float32) if want_message else None
+    acc = torch.empty((B, L, nhead, D), device=q.device, dtype=torch.float32) if w_level is not None else None
+    ts = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.float32)
+    ti = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.int64)
+    with torch.cuda.device(q.device):
+        _lib.check(l.casmtr_qta_coarse_level_fwd(_ptr(q), _ptr(k), _ptr(v), 1.0 / D ** 0.5, topk,
+                                                 0.0 if w_level is None else float(w_level), _ptr(ws), _ptr(msg),
+                                                 _ptr(acc), _ptr(ts), _ptr(ti), B, L, S, nhead, D, _stream()),
+                   "qta_coarse_level_fwd")
+    return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti, probs_ws=ws)
+
+
+def qta_fine_level(q, key, value, prev_idx, hw0, hw1, nhead, topk, w_level=None, acc_in=None, want_message=True):
+    """q [B,h0*w0,C], key/value [B,h1*w1,C], prev_idx [B,L/4,Kp,H] -> dict(message, acc, topk_score, topk_idx)."""
+    _chk(q, "q"), _chk(key, "key"), _chk(value, "value"), _chk(prev_idx, "prev_idx", torch.int64), _chk(acc_in, "acc_in")
+    B, L, Cc = q.shape
+    (h0, w0), (h1, w1) = hw0, hw1
+    D, Kp = Cc // nhead, prev_idx.shape[2]
+    dev = q.device
+    msg = torch.empty((B, L, nhead, D), device=dev, dtype=torch.float32) if want_message else None
+    acc = torch.empty((B, L, nhead, D), device=dev, dtype=torch.float32) if w_level is not None else None
+    ts = torch.empty((B, L, topk, nhead), device=dev, dtype=torch.float32) if topk > 0 else None
+    ti = torch.empty((B, L, topk, nhead), device=dev, dtype=torch.int64) if topk > 0 else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().casmtr_qta_fine_level_fwd(_ptr(q), _ptr(key), _ptr(value), _ptr(prev_idx), 1.0 / D ** 0.5,
+                                                         topk, 0.0 if w_level is None else float(w_level), _ptr(acc_in),
+                                                         _ptr(msg), _ptr(acc), _ptr(ts), _ptr(ti), B, h0, w0, h1, w1,
+                                                         nhead, D, Kp, _stream()), "qta_fine_level_fwd")
+    return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti)
+
+
+def cascade_attn(q, key, value, topk_pos, hw0, hw1, nhead, dilated=1, rel_pos=None, want_idx=True):
+    """q [B,h0*w0,C], key/value [B,h1*w1,C], topk_pos [B,L/4,KW,2] -> (message [B,L,C], up_idx [B,L,4KW] | None)."""
+    _chk(q, "q"), _chk(key, "key"), _chk(value, "value"), _chk(topk_pos, "topk_pos", torch.int64), _chk(rel_pos, "rel_pos")
+    B, L, Cc = q.shape
+    (h0, w0), (h1, w1) = hw0, hw1
+    KW, D = topk_pos.shape[2], Cc // nhead
+    msg = torch.empty((B, L, Cc), device=q.device, dtype=torch.float32)
+    up = torch.empty((B, L, 4 * KW), device=q.device, dtype=torch.int64) if want_idx else None
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().casmtr_cascade_attn_fwd(_ptr(q), _ptr(key), _ptr(value), _ptr(topk_pos), _ptr(rel_pos),
+                                                       1.0 / D ** 0.5, int(dilated), _ptr(msg), _ptr(up), B, h0, w0, h1,
+                                                       w1, nhead, D, KW, _stream()), "cascade_attn_fwd")
+    return msg, up
+
+
+def window_warp_idx(idx, H, W, ws=5):
+    _chk(idx, "idx", torch.int64)
+    B, N = idx.shape
+    out = torch.empty((B, N, ws * ws, 2), device=idx.device, dtype=torch.int64)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.lib().casmtr_window_warp_idx(_ptr(idx), _ptr(out), B, N, H, W, ws, _stream()), "window_warp_idx")
+    return out
+
+
+def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=None, mask1=None, valid_hw=None,
+                 recip=True, want_conf=True):
+    """CoarseMatching numerics.  Returns a dict; match lists are capacity-sized, `n` is a device int64 scalar."""
+    _chk(feat0, "feat0"), _chk(feat1, "feat1")
+    mask0, mask1 = _u8(mask0), _u8(mask1)
+    _chk(valid_hw, "valid_hw", torch.int32)
+    B, L, Cc = feat0.shape
+    S = feat1.shape[1]
+    dev = feat0.device
+    l = _lib.lib()
+    sim = torch.empty((B, L, S), device=dev, dtype=torch.float32)
+    ws = torch.empty(l.casmtr_dual_softmax_ws_bytes(B, L, S), device=dev, dtype=torch.uint8)
+    ni01 = torch.empty((B, L), device=dev, dtype=torch.int64)
+    nc01 = torch.empty((B, L), device=dev, dtype=torch.float32)
+    ni10 = torch.empty((B, S), device=dev, dtype=torch.int64)
+    nc10 = torch.empty((B, S), device=dev, dtype=torch.float32)
+    bi, ii, ji = (torch.empty(B * L, device=dev, dtype=torch.int64) for _ in range(3))
+    mc = torch.empty(B * L, device=dev, dtype=torch.float32)
+    n = torch.zeros(1, device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev):
+        _lib.check(l.casmtr_dual_softmax_fwd(_ptr(feat0), _ptr(feat1), _ptr(mask0), _ptr(mask1), float(temperature),
+                                             int(bool(recip)), float(thr), int(border_rm), _ptr(valid_hw), hw0[0], hw0[1],
+                                             hw1[0], hw1[1], int(bool(want_conf)), _ptr(sim), _ptr(ws), _ptr(ni01),
+                                             _ptr(nc01), _ptr(ni10), _ptr(nc10), _ptr(bi), _ptr(ii), _ptr(ji), _ptr(mc),
+                                             _ptr(n), B, L, S, Cc, _stream()), "dual_softmax_fwd")
+    return dict(conf_matrix=sim if want_conf else None, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
+                next_conf_c10=nc10, b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n)
+
+
+def window_match(feat_q, feat_k, idx, temperature=1.0, mask_q=None, mask_k=None, recip=True, want_conf=True, hw=None):
+    _chk(feat_q, "feat_q"), _chk(feat_k, "feat_k"), _chk(idx, "idx", torch.int64)
+    mask_q, mask_k = _u8(mask_q), _u8(mask_k)
+    B, N, Cc = feat_q.shape
+    M, K = feat_k.shape[1], idx.shape[2]
+    dev = feat_q.device
+    conf = torch.empty((B, N, K), device=dev, dtype=torch.float32) if want_conf else None
+    nc = torch.empty((B, N), device=dev, dtype=torch.float32)
+    ni = torch.empty((B, N), device=dev, dtype=torch.int64)
+    h, w = hw if hw is not None else (0, 0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().casmtr_window_match_fwd(_ptr(feat_q), _ptr(feat_k), _ptr(idx), _ptr(mask_q), _ptr(mask_k),
+                                                       float(temperature), int(bool(recip)), _ptr(conf), _ptr(nc), _ptr(ni),
+                                                       B, N, M, K, Cc, int(h), int(w), _stream()), "window_match_fwd")
+    return dict(conf_matrix=conf, next_conf=nc, next_idx=ni)
+
+
+def nms_select(next_conf01, next_idx01, next_idx10, hw0, hw1, nms_window=5, test_thr=0.2, pre=(), border_rm=0,
+               valid_hw=None, double_check=True):
+    """pre: sequence of (pre_conf [B,hp*wp], (hp,wp), pre_thr), at most 2.  Returns dict with device count `n`."""
+    _chk(next_conf01, "next_conf01"), _chk(next_idx01, "next_idx01", torch.int64), _chk(next_idx10, "next_idx10", torch.int64)
+    _chk(valid_hw, "valid_hw", torch.int32)
+    B, N = next_conf01.shape
+    dev = next_conf01.device
+    pre = list(pre)
+    if len(pre) > 2:
+        raise RuntimeError("at most two previous stages are supported")
+    for p in pre:
+        _chk(p[0], "pre_conf")
+    pre += [(None, (1, 1), 0.0)] * (2 - len(pre))
+    l = _lib.lib()
+    ws = torch.empty(l.casmtr_nms_select_ws_bytes(B, hw0[0], hw0[1]), device=dev, dtype=torch.uint8)
+    bi, ii, ji = (torch.empty(B * N, device=dev, dtype=torch.int64) for _ in range(3))
+    mc = torch.empty(B * N, device=dev, dtype=torch.float32)
+    n = torch.zeros(1, device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev):
+        _lib.check(l.casmtr_nms_select_fwd(_ptr(next_conf01), _ptr(next_idx01), _ptr(next_idx10), int(nms_window),
+                                           float(test_thr), _ptr(pre[0][0]), pre[0][1][0], pre[0][1][1], float(pre[0][2]),
+                                           _ptr(pre[1][0]), pre[1][1][0], pre[1][1][1], float(pre[1][2]), int(border_rm),
+                                           _ptr(valid_hw), int(bool(double_check)), _ptr(ws), _ptr(bi), _ptr(ii), _ptr(ji),
+                                           _ptr(mc), _ptr(n), B, hw0[0], hw0[1], hw1[0], hw1[1], _stream()),
+                   "nms_select_fwd")
+    return dict(b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n, keep_ws=ws)

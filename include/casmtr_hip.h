@@ -1,0 +1,138 @@
+/*
+ * casmtr_hip.h -- C ABI of libcasmtr_hip.so: CasMTR's cascaded-matching hot path on MI355X (gfx950).
+ *
+ * Plain pointers and sizes only (no torch types).  Every pointer is a DEVICE pointer to a dense row-major
+ * tensor; fp32 values, int64 indices (what the reference's extensions take: packed_accessor32<long,...>,
+ * score_computation_kernal.cu:24-26).  `stream` is a hipStream_t.  Return value: 0 on success, a hipError_t
+ * code, or CASMTR_ERR_UNSUPPORTED (1001) when a shape is outside what the kernel is built for -- callers must
+ * surface that as an error, never route around it on the CPU.  All launches are asynchronous on `stream`.
+ *
+ * Citations are relative to the reference checkout (ewrfcas/CasMTR).
+ */
+#ifndef CASMTR_HIP_H
+#define CASMTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* casmtr_stream_t; /* hipStream_t */
+
+#define CASMTR_ABI_VERSION 1
+int casmtr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Drop-in primitives: one entry point per pybind function of the reference's three extensions.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* score_computation_cuda.score_forward      (score_computation.cpp:11-20,36 ; kernel score_computation_kernal.cu:21-92)
+ *   q [B,N1,4,H,D], key [B,N2,H,D], idx [B,N1,K,H] -> out [B,N1,4,K,H] = sum_d q*key[idx]                      */
+int casmtr_qta_score_fwd(const float* q, const float* key, const int64_t* idx, float* out,
+                         int B, int N1, int N2, int K, int H, int D, casmtr_stream_t stream);
+/* score_computation_cuda.score_backward     (score_computation.cpp:22-33,37 ; kernel :94-184)
+ *   grad [B,N1,4,K,H] -> dq [B,N1,4,H,D] (overwritten), dkey [B,N2,H,D] (zeroed, then accumulated)             */
+int casmtr_qta_score_bwd(const float* grad, const float* q, const float* key, const int64_t* idx,
+                         float* dq, float* dkey, int B, int N1, int N2, int K, int H, int D, casmtr_stream_t stream);
+
+/* value_aggregation_cuda.value_aggregation_forward  (value_aggregation.cpp:9-31,63 ; kernel value_aggregation_kernel.cu:21-53)
+ *   score [B,N,K,H], value [B,M,H,D], idx [B,N,K,H] -> out [B,N,H,D] (caller-allocated, overwritten)           */
+int casmtr_qta_value_agg_fwd(const float* score, const float* value, const int64_t* idx, float* out,
+                             int B, int N, int K, int H, int M, int D, casmtr_stream_t stream);
+/* value_aggregation_cuda.value_aggregation_backward (value_aggregation.cpp:33-60,64 ; kernel :55-86)
+ *   grad_score [B,N,K,H] overwritten; grad_value [B,M,H,D] ACCUMULATED into (caller zero-initialises it)       */
+int casmtr_qta_value_agg_bwd(const float* grad_out, const float* score, const float* value, const int64_t* idx,
+                             float* grad_score, float* grad_value, int B, int N, int K, int H, int M, int D,
+                             casmtr_stream_t stream);
+
+/* fast_score_computation.score_forward      (score_cuda/src/score_computation.cpp:8-17,30 ; kernel score_computation_kernel.cu:22-65)
+ *   q [B,N1,C], key [B,N2,C], idx [B,N1,K] -> out [B,N1,K]                                                     */
+int casmtr_window_score_fwd(const float* q, const float* key, const int64_t* idx, float* out,
+                            int B, int N1, int N2, int K, int C, casmtr_stream_t stream);
+/* fast_score_computation.score_backward     (score_cuda/src/score_computation.cpp:19-27,31 ; kernel :67-123)    */
+int casmtr_window_score_bwd(const float* grad, const float* q, const float* key, const int64_t* idx,
+                            float* dq, float* dkey, int B, int N1, int N2, int K, int C, casmtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused per-level kernels (what QTAttB / CascadeQTAttB / CoarseMatching / CascadeMatching run).
+ * Token layout everywhere: [B, h*w, H, D] == [B, h*w, C], raster order of the h x w grid.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* [B,C,h,w] -> [B,h*w,C]   (the `rearrange(x, "b c h w -> b (h w) c")...contiguous()` at
+ * cuda_imp/.../modules/quadtree_attention.py:165-167,185-186,413-414)                                           */
+int casmtr_nchw_to_tokens(const float* x, float* out, int B, int C, int HW, casmtr_stream_t stream);
+
+/* QTAttB.process_coarse_level (modules/quadtree_attention.py:161-178): dense QK^T (fp32 MFMA) -> softmax over S
+ * -> top-k -> A.V.   q [B,L,H,D], k/v [B,S,H,D].
+ *   logits_ws : workspace [B,H,L,S_pad] floats, S_pad = round_up(S,64)  (also receives A if want_A, same layout)
+ *   message [B,L,H,D]; acc_out [B,L,H,D] = message * w_level (NULL to skip); topk_score/topk_idx [B,L,topk,H]  */
+int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const float* v, float temp, int topk, float w_level,
+                                float* logits_ws, float* message, float* acc_out, float* topk_score,
+                                int64_t* topk_idx, int B, int L, int S, int H, int D, casmtr_stream_t stream);
+size_t casmtr_qta_coarse_level_ws_floats(int B, int L, int S, int H);
+
+/* QTAttB.process_fine_level + its share of the message merge (modules/quadtree_attention.py:180-229,262-284).
+ *   q [B,h0*w0,H,D]; key/value [B,h1*w1,H,D]; prev_idx [B,(h0/2)*(w0/2),Kp,H] absolute key index on the
+ *   (h1/2)x(w1/2) grid (the previous level's topk_idx); candidates = 4 children per entry, parent-major.
+ *   message (nullable) [B,L,H,D]; acc_out (nullable) = acc_in[parent] + message*w_level; acc_in nullable (0).
+ *   topk == 0 skips selection (finest level: the reference computes and discards it, :219-227).
+ *   Outputs are in raster order of the h0 x w0 grid (i.e. after the un-quad rearrange :226-227).               */
+int casmtr_qta_fine_level_fwd(const float* q, const float* key, const float* value, const int64_t* prev_idx,
+                              float temp, int topk, float w_level, const float* acc_in, float* message,
+                              float* acc_out, float* topk_score, int64_t* topk_idx,
+                              int B, int h0, int w0, int h1, int w1, int H, int D, int Kp, casmtr_stream_t stream);
+
+/* CascadeQTAttB.forward (modules/quadtree_attention.py:400-452).
+ *   q [B,h0*w0,C]; key/value [B,h1*w1,C]; topk_pos [B,(h0/2)*(w0/2),KW,2] (row,col) on the (h1/2)x(w1/2) grid;
+ *   rel_pos nullable [B,nhead,h0*w0,4*KW]; message [B,h0*w0,C]; up_idx nullable [B,h0*w0,4*KW] int64.          */
+int casmtr_cascade_attn_fwd(const float* q, const float* key, const float* value, const int64_t* topk_pos,
+                            const float* rel_pos, float temp, int dilated, float* message, int64_t* up_idx,
+                            int B, int h0, int w0, int h1, int w1, int nhead, int D, int KW, casmtr_stream_t stream);
+
+/* CascadeFeatureTransformer.get_window_warp_idx, 'window' propagation (src/model/modules/transformer.py:416-440):
+ *   idx [B,N] on an HxW grid -> out [B,N,ws*ws,2] (row,col) of the ws x ws window shifted inside the grid.      */
+int casmtr_window_warp_idx(const int64_t* idx, int64_t* out, int B, int N, int H, int W, int ws,
+                           casmtr_stream_t stream);
+
+/* CoarseMatching.forward + get_coarse_match (src/model/functions/coarse_matching.py:40-153).
+ *   feat0 [B,L,C], feat1 [B,S,C]; mask0 [B,L] / mask1 [B,S] uint8 or NULL; valid_hw [B,4] int32 (h0,w0,h1,w1) or NULL.
+ *   sim_ws   : [B,L,S] floats -- receives the similarity matrix, and conf_matrix in place when want_conf != 0
+ *   stats_ws : casmtr_dual_softmax_ws_bytes(...) bytes of scratch
+ *   next_idx01/next_conf01 [B,L]; next_idx10/next_conf10 [B,S];
+ *   b_ids/i_ids/j_ids [B*L] int64, mconf [B*L] float (capacity), n_matches: device int64 (count)                */
+int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                            float temperature, int recip, float thr, int border_rm, const int32_t* valid_hw,
+                            int h0c, int w0c, int h1c, int w1c, int want_conf, float* sim_ws, void* stats_ws,
+                            int64_t* next_idx01, float* next_conf01, int64_t* next_idx10, float* next_conf10,
+                            int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches,
+                            int B, int L, int S, int C, casmtr_stream_t stream);
+size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S);
+
+/* CascadeMatching.forward, one direction per call (src/model/functions/cascade_matching.py:63-161).
+ *   feat_q [B,N,C], feat_k [B,M,C], idx [B,N,K]; mask_q [B,N] / mask_k [B,M] uint8 or NULL;
+ *   (h,w): the query grid, used only to let the 4 children of a quad share their (identical) window rows;
+ *   conf nullable [B,N,K]; next_conf [B,N]; next_idx [B,N] (= idx[argmax])                                      */
+int casmtr_window_match_fwd(const float* feat_q, const float* feat_k, const int64_t* idx, const uint8_t* mask_q,
+                            const uint8_t* mask_k, float temperature, int recip, float* conf, float* next_conf,
+                            int64_t* next_idx, int B, int N, int M, int K, int C, int h, int w,
+                            casmtr_stream_t stream);
+
+/* CascadeMatching.get_coarse_match, inference branch (cascade_matching.py:170-261,317-331) with
+ * PostProcess.apply for method None / 'maxpool_nms' (post_processing.py:41-44,111-121) and
+ * mask_window_border[_with_padding] (cascade_functions.py:120-172).
+ *   nms_window 0 = no NMS; pre_conf{0,1} nullable [B,hp*wp]; ws: casmtr_nms_select_ws_bytes(...) bytes scratch;
+ *   outputs in (b,i) order with capacity B*H0*W0, count in *n_matches (device).                                 */
+int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* next_idx01, const int64_t* next_idx10,
+                          int nms_window, float test_thr, const float* pre_conf0, int hp0, int wp0, float pre_thr0,
+                          const float* pre_conf1, int hp1, int wp1, float pre_thr1, int border_rm,
+                          const int32_t* valid_hw, int double_check, void* ws, int64_t* b_ids,
+                          int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches,
+                          int B, int H0, int W0, int H1, int W1, casmtr_stream_t stream);
+size_t casmtr_nms_select_ws_bytes(int B, int H0, int W0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASMTR_HIP_H */

@@ -1,0 +1,245 @@
+"""GPU parity: every C-ABI entry point of libcasmtr_hip.so against the CPU oracle on the same seeded inputs.
+
+Bar: indices bit-exact (int64 compare), fp32 dot-product outputs bit-exact (same fmaf chain), softmax-derived values
+within 1e-4 (north_star) -- in practice ~1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_inputs import CASES, make_inputs
+from parity_utils import assert_close, load_golden, match_set
+
+pytestmark = pytest.mark.gpu
+SOFTMAX_TOL = 1e-4
+DEV = "cuda:0"
+
+
+def T(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from casmtr_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("name", list(CASES["ops"]))
+def test_primitives_bit_exact(ops, name):
+    inp = make_inputs("ops", name)
+    s = ops.qta_score_fwd(T(inp["q"]), T(inp["key"]), T(inp["idx"]))
+    so = oracle.qta_score_fwd(inp["q"], inp["key"], inp["idx"])
+    assert np.array_equal(N(s), so), "qta_score_fwd must be bit-exact (same fmaf chain)"
+    A = np.random.default_rng(0).random(so.shape, dtype=np.float32)
+    B, N1, _, K, H = A.shape
+    idx5 = np.repeat(inp["idx"][:, :, None], 4, axis=2).reshape(B, N1 * 4, K, H)
+    out = torch.zeros((B, N1 * 4, H, inp["value"].shape[-1]), device=DEV)
+    ops.qta_value_agg_fwd(T(A.reshape(B, N1 * 4, K, H)), T(inp["value"]), T(idx5), out)
+    mo = oracle.qta_value_agg_fwd(A.reshape(B, N1 * 4, K, H), inp["value"], idx5)
+    assert np.array_equal(N(out), mo), "qta_value_agg_fwd must be bit-exact (sequential-k fmaf chain)"
+    ws = ops.window_score_fwd(T(inp["wq"]), T(inp["wkey"]), T(inp["widx"]))
+    assert np.array_equal(N(ws), oracle.window_score_fwd(inp["wq"], inp["wkey"], inp["widx"]))
+    # golden (reference python) within fp32 summation-order noise
+    g = load_golden("ops", name)
+    assert_close(N(s), g["score"], 5e-5, "score vs reference python")
+
+
+@pytest.mark.parametrize("name", list(CASES["ops"]))
+def test_primitives_backward(ops, name):
+    inp = make_inputs("ops", name)
+    r = np.random.default_rng(1)
+    B, N1, _, H, D = inp["q"].shape
+    K = inp["idx"].shape[2]
+    g = r.standard_normal((B, N1, 4, K, H), dtype=np.float32)
+    dq, dk = ops.qta_score_bwd(T(g), T(inp["q"]), T(inp["key"]), T(inp["idx"]))
+    dqo, dko = oracle.qta_score_bwd(g, inp["q"], inp["key"], inp["idx"])
+    assert_close(N(dq), dqo, 2e-4, "score dq")
+    assert_close(N(dk), dko, 2e-4, "score dkey (atomics)")
+    sc = r.random((B, N1 * 4, K, H), dtype=np.float32)
+    idx5 = np.repeat(inp["idx"][:, :, None], 4, axis=2).reshape(B, N1 * 4, K, H)
+    go = r.standard_normal((B, N1 * 4, H, D), dtype=np.float32)
+    gs = torch.zeros((B, N1 * 4, K, H), device=DEV)
+    gv = torch.zeros(inp["value"].shape, device=DEV)
+    ops.qta_value_agg_bwd(T(go), T(sc), T(inp["value"]), T(idx5), gs, gv)
+    gso, gvo = oracle.qta_value_agg_bwd(go, sc, inp["value"], idx5)
+    assert_close(N(gs), gso, 2e-4, "agg grad_score")
+    assert_close(N(gv), gvo, 2e-4, "agg grad_value (atomics)")
+    gw = r.standard_normal(inp["widx"].shape, dtype=np.float32)
+    dq, dk = ops.window_score_bwd(T(gw), T(inp["wq"]), T(inp["wkey"]), T(inp["widx"]))
+    dqo, dko = oracle.window_score_bwd(gw, inp["wq"], inp["wkey"], inp["widx"])
+    assert_close(N(dq), dqo, 5e-4, "window dq")
+    assert_close(N(dk), dko, 5e-4, "window dkey (atomics)")
+
+
+def test_nchw_to_tokens(ops):
+    x = np.random.default_rng(2).standard_normal((2, 70, 9, 13), dtype=np.float32)
+    out = ops.nchw_to_tokens(T(x))
+    assert np.array_equal(N(out), x.transpose(0, 2, 3, 1).reshape(2, 9 * 13, 70))
+
+
+def _tok(x):
+    B, C, h, w = x.shape
+    return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(B, h * w, C))
+
+
+@pytest.mark.parametrize("name", list(CASES["qtattb"]))
+def test_qtattb_levels(ops, name):
+    """coarse + fine level kernels chained exactly like QTAttB.forward; indices bit-exact vs oracle AND vs the reference."""
+    inp = make_inputs("qtattb", name)
+    cfg = CASES["qtattb"][name]
+    H, topks = cfg["nhead"], cfg["topks"]
+    final_o, lv_o = oracle.qtattb_forward(inp["queries"], inp["keys"], inp["values"], inp["weight"], H, topks)
+    g = load_golden("qtattb", name)
+    w = np.asarray(inp["weight"], np.float32)
+    e = np.exp(w - w.max()); wsm = (e / e.sum()).astype(np.float32)
+    acc = prev = None
+    for i in range(3):
+        q, k, v = (_tok(inp[n][2 - i]) for n in ("queries", "keys", "values"))
+        h0, w0 = inp["queries"][2 - i].shape[2:]
+        h1, w1 = inp["keys"][2 - i].shape[2:]
+        if i == 0:
+            out = ops.qta_coarse_level(T(q), T(k), T(v), H, topks[0], w_level=float(wsm[0]))
+        else:
+            out = ops.qta_fine_level(T(q), T(k), T(v), prev, (h0, w0), (h1, w1), H, topks[i], w_level=float(wsm[i]), acc_in=acc)
+        acc, prev = out["acc"], out["topk_idx"]
+        assert np.array_equal(N(out["topk_idx"]), lv_o[i]["topk_idx"]), f"level {i} top-k indices differ from the oracle"
+        assert np.array_equal(N(out["topk_idx"]), g[f"L{i}_topk_idx"].astype(np.int64)), f"level {i} top-k differ from the reference"
+        assert_close(N(out["topk_score"]), lv_o[i]["topk_score"], SOFTMAX_TOL, f"level {i} topk_score")
+        assert_close(N(out["message"]), lv_o[i]["message"], SOFTMAX_TOL, f"level {i} message")
+    assert_close(N(acc), final_o, SOFTMAX_TOL, "final message vs oracle")
+    assert_close(N(acc), g["final"], SOFTMAX_TOL, "final message vs reference python")
+
+
+@pytest.mark.parametrize("name", list(CASES["cascade_attn"]))
+def test_cascade_attn(ops, name):
+    inp = make_inputs("cascade_attn", name)
+    cfg = CASES["cascade_attn"][name]
+    g = load_golden("cascade_attn", name)
+    hc, wc = cfg["coarse_hw"]
+    tp = ops.window_warp_idx(T(inp["coarse_idx"]), hc, wc, cfg["ws"])
+    assert np.array_equal(N(tp), g["topk_pos"].astype(np.int64))
+    h, w = 2 * hc, 2 * wc
+    rel = T(inp["rel_pos"]) if cfg.get("rel_pos") else None
+    q, k, v = (ops.nchw_to_tokens(T(inp[n])) for n in ("q", "k", "v"))
+    msg, up = ops.cascade_attn(q, k, v, tp, (h, w), (h, w), cfg["nhead"], rel_pos=rel)
+    assert np.array_equal(N(up), g["upsampled_idx"].astype(np.int64))
+    assert_close(N(msg), g["message"], SOFTMAX_TOL, "message vs reference python")
+    mo, _ = oracle.cascade_attn(N(q), N(k), N(v), N(tp), (h, w), (h, w), cfg["nhead"], rel_pos=inp.get("rel_pos"))
+    assert_close(N(msg), mo, 1e-5, "message vs oracle")
+
+
+def _valid_hw(m0, m1):
+    return np.stack([m0.sum(1).max(-1), m0.sum(2).max(-1), m1.sum(1).max(-1), m1.sum(2).max(-1)], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("recip", [False, True])
+@pytest.mark.parametrize("name", list(CASES["coarse_matching"]))
+def test_dual_softmax(ops, name, recip):
+    inp = make_inputs("coarse_matching", name)
+    cfg = CASES["coarse_matching"][name]
+    B = cfg["B"]
+    kw = dict(temperature=cfg.get("T", 0.1), thr=cfg.get("thr", 0.2), border_rm=cfg.get("border_rm", 0))
+    m0 = m1 = valid = None
+    if cfg.get("masks"):
+        m0, m1 = inp["mask0"].reshape(B, -1), inp["mask1"].reshape(B, -1)
+        valid = _valid_hw(inp["mask0"], inp["mask1"])
+    o = oracle.dual_softmax(inp["feat0"], inp["feat1"], cfg["hw0"], cfg["hw1"], mask0=m0, mask1=m1, valid_hw=valid,
+                            recip=recip, want_conf=True, **kw)
+    d = ops.dual_softmax(T(inp["feat0"]), T(inp["feat1"]), cfg["hw0"], cfg["hw1"], mask0=None if m0 is None else T(m0),
+                         mask1=None if m1 is None else T(m1), valid_hw=None if valid is None else T(valid), recip=recip,
+                         want_conf=True, **kw)
+    assert np.array_equal(N(d["next_idx_c01"]), o["next_idx_c01"]), "row argmax must be bit-exact"
+    assert np.array_equal(N(d["next_idx_c10"]), o["next_idx_c10"]), "column argmax must be bit-exact"
+    assert_close(N(d["next_conf_c01"]), o["next_conf_c01"], SOFTMAX_TOL, "next_conf_c01")
+    assert_close(N(d["next_conf_c10"]), o["next_conf_c10"], SOFTMAX_TOL, "next_conf_c10")
+    assert_close(N(d["conf_matrix"]), o["conf_matrix"], SOFTMAX_TOL, "conf_matrix")
+    n = int(d["n"].item())
+    got = match_set(N(d["b_ids"][:n]), N(d["i_ids"][:n]), N(d["j_ids"][:n]))
+    want = match_set(o["b_ids"], o["i_ids"], o["j_ids"])
+    for t in got ^ want:  # only threshold-borderline entries may differ (expf differs by ulps between CPU and GPU)
+        assert abs(o["conf_matrix"][t] - kw["thr"]) < 1e-5, f"match list differs at {t}"
+    assert len(got ^ want) <= 1
+    if got == want:
+        assert np.array_equal(N(d["i_ids"][:n]), o["i_ids"]) and np.array_equal(N(d["j_ids"][:n]), o["j_ids"]), "order"
+        assert_close(N(d["mconf"][:n]), o["mconf"], SOFTMAX_TOL, "mconf")
+    if not recip:  # the fixtures come from the reference on CPU (true division)
+        g = load_golden("coarse_matching", name)
+        assert (N(d["next_idx_c01"]) != g["next_idx_c01"]).mean() <= 1e-3
+        assert_close(N(d["next_conf_c01"]), g["next_conf_c01"], SOFTMAX_TOL, "next_conf_c01 vs reference python")
+        gs = match_set(g["b_ids"], g["i_ids"], g["j_ids"])
+        assert len(got ^ gs) <= 1
+
+
+@pytest.mark.parametrize("recip", [False, True])
+@pytest.mark.parametrize("name", list(CASES["cascade_matching"]))
+def test_window_match_and_select(ops, name, recip):
+    inp = make_inputs("cascade_matching", name)
+    cfg = CASES["cascade_matching"][name]
+    g = load_golden("cascade_matching", name)
+    hc, wc = cfg["coarse_hw"]
+    h, w = 2 * hc, 2 * wc
+    B = cfg["B"]
+    idx01, idx10 = g["idx_c01"].astype(np.int64), g["idx_c10"].astype(np.int64)
+    mq = mk = valid = None
+    if cfg.get("masks"):
+        mq, mk = inp["mask0"].reshape(B, -1), inp["mask1"].reshape(B, -1)
+        valid = _valid_hw(inp["mask0"], inp["mask1"])
+    tm = lambda m: None if m is None else T(m)
+    for quad in (True, False):
+        d01 = ops.window_match(T(inp["feat0"]), T(inp["feat1"]), T(idx01), 1.0, tm(mq), tm(mk), recip=recip, hw=(h, w) if quad else None)
+        d10 = ops.window_match(T(inp["feat1"]), T(inp["feat0"]), T(idx10), 1.0, tm(mk), tm(mq), recip=recip, hw=(h, w) if quad else None)
+        o01 = oracle.window_match(inp["feat0"], inp["feat1"], idx01, 1.0, mq, mk, recip=recip)
+        o10 = oracle.window_match(inp["feat1"], inp["feat0"], idx10, 1.0, mk, mq, recip=recip)
+        assert np.array_equal(N(d01["next_idx"]), o01["next_idx"]), "next_idx_c01 must be bit-exact"
+        assert np.array_equal(N(d10["next_idx"]), o10["next_idx"]), "next_idx_c10 must be bit-exact"
+        assert_close(N(d01["conf_matrix"]), o01["conf_matrix"], SOFTMAX_TOL, "conf_matrix01")
+        assert_close(N(d01["next_conf"]), o01["next_conf"], SOFTMAX_TOL, "next_conf_c01")
+        assert_close(N(d10["next_conf"]), o10["next_conf"], SOFTMAX_TOL, "next_conf_c10")
+    # generic (non-identical) index rows exercise the per-token restaging path
+    r = np.random.default_rng(5)
+    ridx = r.integers(0, h * w, idx01.shape, dtype=np.int64)
+    dg = ops.window_match(T(inp["feat0"]), T(inp["feat1"]), T(ridx), 1.0, recip=recip, hw=(h, w))
+    og = oracle.window_match(inp["feat0"], inp["feat1"], ridx, 1.0, recip=recip)
+    assert np.array_equal(N(dg["next_idx"]), og["next_idx"])
+    assert_close(N(dg["conf_matrix"]), og["conf_matrix"], SOFTMAX_TOL, "generic conf")
+    # selection: fed with the reference's own stage outputs it is pure comparison logic -> exact vs the fixture
+    sel = ops.nms_select(T(g["next_conf_c01"]), T(g["next_idx_c01"].astype(np.int64)), T(g["next_idx_c10"].astype(np.int64)),
+                         (h, w), (h, w), nms_window=5 if cfg.get("nms", True) else 0, test_thr=cfg.get("test_thr", 0.2),
+                         pre=[(T(inp["pre_conf"]), (hc, wc), cfg.get("pre_thr", 0.2))], border_rm=cfg.get("border_rm", 2),
+                         valid_hw=None if valid is None else T(valid), double_check=cfg.get("double_check", True))
+    n = int(sel["n"].item())
+    assert n == len(g["b_ids"])
+    assert np.array_equal(N(sel["b_ids"][:n]), g["b_ids"].astype(np.int64))
+    assert np.array_equal(N(sel["i_ids"][:n]), g["i_ids"].astype(np.int64))
+    assert np.array_equal(N(sel["j_ids"][:n]), g["j_ids"].astype(np.int64))
+    assert np.array_equal(N(sel["mconf"][:n]), g["mconf"])
+
+
+def test_nms_keep_one_fallback(ops):
+    B, h, w = 3, 8, 8
+    conf = torch.zeros((B, h * w), device=DEV)
+    idx = torch.arange(h * w, device=DEV).repeat(B, 1)
+    sel = ops.nms_select(conf, idx, idx, (h, w), (h, w), nms_window=5, test_thr=0.2)
+    n = int(sel["n"].item())
+    assert n == B and N(sel["b_ids"][:n]).tolist() == [0, 1, 2] and N(sel["i_ids"][:n]).tolist() == [0, 0, 0]
+    o = oracle.nms_select(N(conf), N(idx), N(idx), (h, w), (h, w), nms_window=5, test_thr=0.2)
+    assert o["b_ids"].tolist() == [0, 1, 2]
+
+
+def test_contract_errors(ops):
+    q = torch.zeros((1, 4, 4, 2, 32), device=DEV)
+    key = torch.zeros((1, 16, 2, 32), device=DEV)
+    idx = torch.zeros((1, 4, 8, 2), device=DEV, dtype=torch.int64)
+    with pytest.raises(RuntimeError):
+        ops.qta_score_fwd(q.cpu(), key, idx)            # not device resident (score_computation.cpp:6)
+    with pytest.raises(RuntimeError):
+        ops.qta_score_fwd(q.transpose(1, 2), key, idx)   # not contiguous (score_computation.cpp:7)
+    with pytest.raises(RuntimeError):
+        ops.qta_score_fwd(q, key, idx.int())            # index dtype
