@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- image pairs/sec through CasMTR-4c's cascaded-matching hot path at 832x832 on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot-path chain (casmtr_amd/pipeline.py) over a batch of synthetic pairs that is already
+resident in HBM: 12 QTAttB + CoarseMatching + 4 CascadeQTAttB + CascadeMatching (+NMS/selection) per pair, followed
+by the gather of the match lists to rank 0.  Image pairs are independent, so ranks shard them with no data-path
+collective (weak scaling: --batch pairs per GPU); RCCL carries the start-up weight broadcast and the match gather.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     : the dominant kernel's achieved rate vs the gfx950 peak, from HIP events recorded on the launch stream
+  cpu_baseline : the CPU oracle (oracle/, C + OpenMP "port" of the reference algorithm) on the host cores, rank 0, N=1
+  kernels      : per-kernel ms/step breakdown (same events)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from casmtr_amd import _lib, dist as cdist  # noqa: E402
+from casmtr_amd.pipeline import HotPath, HotPathConfig, algorithmic_work, make_synthetic_inputs  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0          # same guide, HBM3E peak (6.3 TB/s achievable)
+
+
+def cpu_baseline(cfg, inp, budget_s=60.0):
+    """The oracle's chain for ONE pair of the same synthetic workload, every call of the chain, all host cores."""
+    import numpy as np
+
+    import oracle
+
+    n = lambda t: t[:1].detach().cpu().numpy()
+    t0 = time.perf_counter()
+    w = inp["weight"].cpu().numpy()
+    for layer in range(cfg.coarse_layers):
+        pairs = ((0, 0), (1, 1)) if layer % 2 == 0 else ((0, 1), (1, 0))
+        for a, b in pairs:
+            oracle.qtattb_forward([n(x) for x in inp[f"cq{a}"]], [n(x) for x in inp[f"ck{b}"]],
+                                  [n(x) for x in inp[f"cv{b}"]], w, cfg.coarse_heads, cfg.coarse_topks)
+    d8 = oracle.dual_softmax(n(inp["feat_8c0"]), n(inp["feat_8c1"]), cfg.hw8, cfg.hw8, cfg.coarse_temperature,
+                             cfg.coarse_thr, cfg.coarse_border_rm, recip=True)
+    tp01 = oracle.window_warp_idx(d8["next_idx_c01"], *cfg.hw8, cfg.window_size)
+    tp10 = oracle.window_warp_idx(d8["next_idx_c10"], *cfg.hw8, cfg.window_size)
+    tok = lambda x: np.ascontiguousarray(n(x).transpose(0, 2, 3, 1).reshape(1, -1, cfg.cascade_dim))
+    for _ in range(cfg.cascade_cross_layers):
+        _, i01 = oracle.cascade_attn(tok(inp["fq0"]), tok(inp["fk1"]), tok(inp["fv1"]), tp01, cfg.hw4, cfg.hw4, cfg.cascade_heads)
+        _, i10 = oracle.cascade_attn(tok(inp["fq1"]), tok(inp["fk0"]), tok(inp["fv0"]), tp10, cfg.hw4, cfg.hw4, cfg.cascade_heads)
+    m01 = oracle.window_match(n(inp["feat_4c0"]), n(inp["feat_4c1"]), i01, cfg.cascade_temperature, recip=True)
+    m10 = oracle.window_match(n(inp["feat_4c1"]), n(inp["feat_4c0"]), i10, cfg.cascade_temperature, recip=True, want_conf=False)
+    sel = oracle.nms_select(m01["next_conf"], m01["next_idx"], m10["next_idx"], cfg.hw4, cfg.hw4, cfg.nms_window,
+                            cfg.cascade_test_thr, [(d8["next_conf_c01"], cfg.hw8, cfg.cascade_pre_thr)],
+                            cfg.cascade_border_rm)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 pair, full chain (12 QTAttB + dual-softmax + 4 CascadeQTAttB + window match x2 + NMS), {dt:.1f} s, "
+                      f"OpenMP on all host cores; {len(sel['b_ids'])} matches"}, sel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--materialize-conf", action="store_true", help="also write the [B,L,S] conf_matrix (drop-in default)")
+    args = ap.parse_args()
+
+    rank, world, local = cdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    _lib.lib()  # fail loudly here if the HIP library is missing
+
+    cfg = HotPathConfig(materialize_conf=args.materialize_conf)
+    B = args.batch
+    model = HotPath(cfg).to(device)
+    inp = make_synthetic_inputs(cfg, B, device, seed=1234 + rank)
+    with torch.no_grad():
+        model.qta.weight.copy_(inp["weight"])
+    cdist.broadcast_parameters(model)          # RCCL broadcast of the (tiny) parameter buffer from rank 0
+
+    def step():
+        out = model(inp)
+        return cdist.gather_matches(out, pairs_per_rank=B)  # counts all-gather + gather of [M,5] / [M] to rank 0
+
+    for _ in range(args.warmup):
+        step()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    cdist.barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.prof_read()
+    _lib.prof_enable(False)
+    dt = cdist.max_over_ranks(dt)
+
+    if rank != 0:
+        cdist.finalize()
+        return
+    ms_step = dt / args.steps * 1e3
+    pairs_s = B * world * args.steps / dt
+    work = algorithmic_work(cfg)
+    kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps} for k, v in prof.items()}
+    dom = max(prof.items(), key=lambda kv: kv[1][0])
+    dname, (dms, dn) = dom
+    avg_ms = dms / dn
+    hbm_work = {"quad_attn_kernel<fine>": None, "quad_attn_kernel<cascade>": work["cascade_bytes"],
+                "window_match_kernel": work["match_bytes"] / 2}
+    if dname == "ds_gemm_kernel":
+        flops = work["coarse_flops"] * B
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        roof = {"kernel": dname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "work_per_launch": f"2*L*S*C*B = {flops:.3e} flop (L=S={cfg.hw8[0] * cfg.hw8[1]}, C={cfg.coarse_dim}, B={B})"}
+    else:
+        byts = (hbm_work.get(dname) or work["qta_bytes"]) * B
+        ach = byts / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": dname, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "work_per_launch": f"{byts:.3e} compulsory bytes"}
+    # chain-level rates for the record (all kernels, not just the dominant one)
+    chain = {"algorithmic_GB_per_pair": round(work["total_bytes"] / 1e9, 4), "algorithmic_GFLOP_per_pair": round(work["total_flops"] / 1e9, 2),
+             "chain_GBps_per_gpu": round(work["total_bytes"] * B * args.steps / dt / 1e9, 1),
+             "chain_TFLOPs_per_gpu": round(work["total_flops"] * B * args.steps / dt / 1e12, 2)}
+    line = {
+        "metric": "image pairs/sec (832x832, CasMTR-4c) cascaded-matching hot path", "value": round(pairs_s, 3),
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{cfg.name}, random-init, batch of {B} synthetic 832x832 pairs per GPU "
+                               f"(BASELINE.json configs[1]); 12 QTAttB + dual-softmax + 4 CascadeQTAttB + cascade matching + NMS per pair",
+                   "pairs_per_gpu": B, "conf_matrix_materialized": bool(cfg.materialize_conf),
+                   "matches_last_step": int(res["n_total"]) if res is not None else None, "parallelism": f"pairs sharded over {world} GPU(s)"},
+        "roofline": roof, "chain": chain, "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb, _ = cpu_baseline(cfg, inp)
+        line["cpu_baseline"] = cb
+        line["gpu_over_cpu"] = round(pairs_s / cb["value"], 1)
+    print(json.dumps(line))
+    cdist.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,26 @@ SIGNATURES = {
     "casmtr_nms_select_fwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _I, _I, _F, _I, _P, _I, _P,
                                    _P, _P, _P, _P, _P] + [_I] * 5 + [_P]),
     "casmtr_nms_select_ws_bytes": (_SZ, [_I] * 3),
+    "casmtr_prof_enable": (None, [_I]),
+    "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "casmtr_prof_name": (C.c_char_p, [_I]),
 }
+PROF_COUNT = 13
+
+
+def prof_enable(on: bool):
+    lib().casmtr_prof_enable(int(on))
+
+
+def prof_read():
+    """-> {kernel name: (total_ms, launches)} for every kernel launched since prof_enable(True)."""
+    out = {}
+    for i in range(PROF_COUNT):
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(lib().casmtr_prof_read(i, C.byref(ms), C.byref(n)), "prof_read")
+        if n.value:
+            out[lib().casmtr_prof_name(i).decode()] = (ms.value, n.value)
+    return out
 
 _lib = None
 

@@ -70,6 +70,15 @@ __device__ __forceinline__ float div_scalar(float x, float s, float inv_s, int r
     return recip ? __fmul_rn(x, inv_s) : __fdiv_rn(x, s);
 }
 
+// prof.hip
+void prof_begin(int id, hipStream_t s);
+void prof_end(int id, hipStream_t s);
+struct ProfScope {
+    int id; hipStream_t s;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
+    ~ProfScope() { prof_end(id, s); }
+};
+
 }  // namespace casmtr
 
 #define CASMTR_CHECK_LAUNCH()                         \

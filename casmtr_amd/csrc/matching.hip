@@ -352,22 +352,31 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_conf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conf_lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ds_gemm_kernel, dim3(NJB, NIB, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws, w, L,
-                       S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, recip);
+    {
+        ProfScope ps(CASMTR_PROF_DS_GEMM, s);
+        hipLaunchKernelGGL(ds_gemm_kernel, dim3(NJB, NIB, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws, w,
+                           L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, recip);
+    }
     CASMTR_CHECK_LAUNCH();
+    prof_begin(CASMTR_PROF_DS_REDUCE, s);
     hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L,
                        w.rmax, w.rsum, next_idx01, next_conf01);
     CASMTR_CHECK_LAUNCH();
     hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, w.cp_a, NIB, S, B * S,
                        w.cmax, w.csum, next_idx10, next_conf10);
+    prof_end(CASMTR_PROF_DS_REDUCE, s);
     CASMTR_CHECK_LAUNCH();
     hipError_t e = hipMemsetAsync(w.rbest, 0, sizeof(unsigned long long) * (size_t)B * L, s);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(w.cbest, 0, sizeof(unsigned long long) * (size_t)B * S, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 255) / 256, (L + 63) / 64, B), dim3(256), conf_lds, s, sim_ws, w, L, S,
-                       want_conf);
+    {
+        ProfScope ps(CASMTR_PROF_DS_CONF, s);
+        hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 255) / 256, (L + 63) / 64, B), dim3(256), conf_lds, s, sim_ws, w, L, S,
+                           want_conf);
+    }
     CASMTR_CHECK_LAUNCH();
+    ProfScope ps(CASMTR_PROF_DS_SELECT, s);
     hipLaunchKernelGGL(ds_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, thr, border_rm, valid_hw, h0c, w0c,
                        h1c, w1c, L, S, B * L);
     CASMTR_CHECK_LAUNCH();
@@ -499,6 +508,7 @@ static int launch_window_match(const float* fq, const float* fk, const int64_t* 
     const bool quad = h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N;
     const float sqrtC = (float)sqrt((double)C);
     const dim3 grid(quad ? (h / 2) * (w / 2) : (N + 3) / 4, B);
+    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
     hipLaunchKernelGGL(window_match_kernel<C>, grid, dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC, 1.0f / sqrtC, T,
                        1.0f / T, recip, conf, next_conf, next_idx, N, M, K, quad ? h : 0, quad ? w : 0);
     CASMTR_CHECK_LAUNCH();
@@ -583,6 +593,7 @@ extern "C" int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* ne
     const int total = B * H0 * W0;
     unsigned char* keep = reinterpret_cast<unsigned char*>(ws);
     int* blk = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align256((size_t)total));
+    ProfScope ps(CASMTR_PROF_NMS_SELECT, s);
     hipLaunchKernelGGL(nms_flag_kernel, dim3((total + 255) / 256), dim3(256), 0, s, next_conf01, next_idx01, next_idx10,
                        nms_window, test_thr, pre_conf0, hp0, wp0, pre_thr0, pre_conf1, hp1, wp1, pre_thr1, border_rm,
                        valid_hw, double_check, keep, B, H0, W0, H1, W1);

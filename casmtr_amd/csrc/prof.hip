@@ -1,0 +1,60 @@
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's live roofline numbers).
+// Disabled by default: prof_begin/prof_end are a branch on a global flag.
+#include <vector>
+#include "common.hpp"
+#include "../../include/casmtr_hip.h"
+
+namespace casmtr {
+static bool g_on = false;
+struct Pair { hipEvent_t a, b; };
+static std::vector<Pair> g_ev[CASMTR_PROF_COUNT];
+static std::vector<Pair> g_free;
+static Pair g_open[CASMTR_PROF_COUNT];
+
+void prof_begin(int id, hipStream_t s) {
+    if (!g_on) return;
+    Pair p;
+    if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    (void)hipEventRecord(p.a, s);
+    g_open[id] = p;
+}
+void prof_end(int id, hipStream_t s) {
+    if (!g_on) return;
+    (void)hipEventRecord(g_open[id].b, s);
+    g_ev[id].push_back(g_open[id]);
+}
+}  // namespace casmtr
+
+using namespace casmtr;
+
+static const char* kNames[CASMTR_PROF_COUNT] = {
+    "ds_gemm_kernel", "ds_reduce_kernel", "ds_conf_kernel", "ds_select", "coarse_logits_kernel", "coarse_row_kernel",
+    "coarse_av_kernel", "quad_attn_kernel<fine>", "quad_attn_kernel<cascade>", "window_match_kernel", "nms_select",
+    "nchw_to_tokens_kernel", "window_warp_idx_kernel"};
+
+extern "C" void casmtr_prof_enable(int on) {
+    for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {
+        for (auto& p : g_ev[i]) g_free.push_back(p);
+        g_ev[i].clear();
+    }
+    g_on = on != 0;
+}
+
+extern "C" int casmtr_prof_read(int id, double* total_ms, int* count) {
+    if (id < 0 || id >= CASMTR_PROF_COUNT) return 1;
+    double tot = 0.0;
+    for (auto& p : g_ev[id]) {
+        hipError_t e = hipEventSynchronize(p.b);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, p.a, p.b);
+        if (e != hipSuccess) return (int)e;
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = (int)g_ev[id].size();
+    return 0;
+}
+
+extern "C" const char* casmtr_prof_name(int id) { return (id >= 0 && id < CASMTR_PROF_COUNT) ? kNames[id] : ""; }

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __rest
 
 extern "C" int casmtr_nchw_to_tokens(const float* x, float* out, int B, int C, int HW, casmtr_stream_t stream) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
+    ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream);
     hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
                        (hipStream_t)stream, x, out, C, HW);
     CASMTR_CHECK_LAUNCH();
@@ -265,6 +266,7 @@ static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    ProfScope ps(MODE == 0 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_CASCADE_ATTN, s);
     hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq, B), dim3(256), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
@@ -486,12 +488,16 @@ extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int Spad = (S + 63) / 64 * 64;
-    hipLaunchKernelGGL(coarse_logits_kernel, dim3(Spad / 64, (L + 63) / 64, B * H), dim3(256), 0, s, q, k, logits_ws,
-                       temp, L, S, Spad, H);
+    {
+        ProfScope ps(CASMTR_PROF_COARSE_LOGITS, s);
+        hipLaunchKernelGGL(coarse_logits_kernel, dim3(Spad / 64, (L + 63) / 64, B * H), dim3(256), 0, s, q, k, logits_ws,
+                           temp, L, S, Spad, H);
+    }
     CASMTR_CHECK_LAUNCH();
     const int rows = B * H * L;
     const dim3 rg((rows + 3) / 4);
     const int E = Spad / 64;
+    prof_begin(CASMTR_PROF_COARSE_ROW, s);
     if (E <= 4)
         hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else if (E <= 8)
@@ -504,9 +510,13 @@ extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const
         hipLaunchKernelGGL(coarse_row_kernel<32>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else
         return CASMTR_ERR_UNSUPPORTED;
+    prof_end(CASMTR_PROF_COARSE_ROW, s);
     CASMTR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(coarse_av_kernel, dim3((L + 127) / 128, B * H), dim3(256), 0, s, logits_ws, v, message, acc_out,
-                       w_level, L, S, Spad, H);
+    {
+        ProfScope ps(CASMTR_PROF_COARSE_AV, s);
+        hipLaunchKernelGGL(coarse_av_kernel, dim3((L + 127) / 128, B * H), dim3(256), 0, s, logits_ws, v, message, acc_out,
+                           w_level, L, S, Spad, H);
+    }
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -533,6 +543,7 @@ extern "C" int casmtr_window_warp_idx(const int64_t* idx, int64_t* out, int B, i
     if (total <= 0) return 0;
     long long blocks = (total * ws * ws + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    ProfScope ps(CASMTR_PROF_WINDOW_WARP, (hipStream_t)stream);
     hipLaunchKernelGGL(window_warp_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, out, total,
                        H, W, ws);
     CASMTR_CHECK_LAUNCH();

@@ -1,0 +1,106 @@
+"""One process per GPU.  Image pairs are independent, so the data path has NO collective; torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm, "gloo" on CPU for tests) carries only
+  * broadcast_parameters(): the start-up broadcast of the flat fp32 parameter buffer from rank 0, and
+  * gather_matches(): the end-of-step gatherv of the match lists to rank 0 (per-rank counts all-gather, then a
+    padded gather of [M,5] fp32 (mkpts0, mkpts1, mconf) and [M] int64 (m_bids, offset to global pair ids)).
+This replaces the role of the reference's detectron2-style pickled gathers on a gloo side group
+(src/utils/comm.py:84-220) for the inference path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """-> (rank, world, local_rank); initialises the default group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()
+
+
+def finalize():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def max_over_ranks(x: float) -> float:
+    if not is_dist():
+        return x
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """contiguous block partition of n_items pairs (what DistributedSampler(shuffle=False) gives the reference,
+    src/lightning/data.py:316, up to interleaving)."""
+    per, rem = divmod(n_items, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0):
+    """One flat fp32 buffer, one broadcast (the hot path owns 3 floats; a full CasMTR-4c is 56 MB -- still one call)."""
+    params = [p for p in module.parameters()] + [b for b in module.buffers()]
+    if not is_dist() or not params:
+        return
+    flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+def gather_matches(out, pairs_per_rank=None, dst: int = 0):
+    """out: dict with m_bids [M] int64, mkpts0/mkpts1 [M,2], mconf [M].  Returns on rank `dst` a dict with the
+    concatenated lists (m_bids offset to global pair ids) and n_total; None elsewhere.  Single process: passthrough."""
+    mk = torch.cat([out["mkpts0"].float(), out["mkpts1"].float(), out["mconf"].float()[:, None]], dim=1)  # [M,5]
+    bids = out["m_bids"]
+    if not is_dist():
+        return {"mk": mk, "m_bids": bids, "n_total": int(mk.shape[0]), "counts": [int(mk.shape[0])]}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = mk.device
+    cnt = torch.tensor([mk.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mmax = max(max(counts), 1)
+    pad_mk = torch.zeros((mmax, 5), dtype=torch.float32, device=dev)
+    pad_b = torch.zeros((mmax,), dtype=torch.int64, device=dev)
+    pad_mk[: mk.shape[0]] = mk
+    if pairs_per_rank is not None:
+        bids = bids + rank * pairs_per_rank
+    pad_b[: bids.shape[0]] = bids
+    if rank == dst:
+        g_mk = [torch.empty_like(pad_mk) for _ in range(world)]
+        g_b = [torch.empty_like(pad_b) for _ in range(world)]
+        dist.gather(pad_mk, g_mk, dst=dst)
+        dist.gather(pad_b, g_b, dst=dst)
+        return {"mk": torch.cat([g[:c] for g, c in zip(g_mk, counts)]),
+                "m_bids": torch.cat([g[:c] for g, c in zip(g_b, counts)]), "n_total": sum(counts), "counts": counts}
+    dist.gather(pad_mk, None, dst=dst)
+    dist.gather(pad_b, None, dst=dst)
+    return None

@@ -1,0 +1,93 @@
+"""CascadeMatching: drop-in for src/model/functions/cascade_matching.py:37-331, inference branch.
+
+forward (:63-168)       -> two casmtr_window_match_fwd launches (0->1 with conf_matrix, 1->0 without)
+get_coarse_match (:170) -> one casmtr_nms_select_fwd (maxpool NMS / thresholds / previous-stage confidence / border
+                           removal / double check / keep-one fallback / ordered compaction)
+The training branch (:264-314, GT window labels, detector heads) is outside the hot path and fails loudly.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .cascade_functions import valid_extents
+from .post_processing import PostProcess
+
+INF = 1e9
+
+
+class CascadeMatching(nn.Module):
+    def __init__(self, config, cas_config, stage=None, div_mode="gpu"):
+        super().__init__()
+        self.config = config
+        self.cas_config = cas_config
+        self.thr = config["thr"]
+        self.test_thr = config["test_thr"]
+        self.pre_thr = config["pre_thr"]
+        self.border_rm = config["border_rm"]
+        self.double_check = config["double_check"]
+        self.train_pad_num_gt_min = config["train_pad_num_gt_min"]
+        self.propagation = cas_config["propagation"]
+        self.dilated = cas_config["dilated"]
+        self.post_process = PostProcess(post_config=cas_config["post_config"])
+        self.detector_mode = cas_config.get("detector_mode", None)
+        self.grid_size = cas_config.get("grid_size", None)
+        self.rt = cas_config["post_config"].get("rt", None)
+        self.rd = cas_config["post_config"].get("rd", None)
+        if self.rt is not None or self.rd is not None:
+            raise NotImplementedError("post_config rt/rd filters are not used by any shipped config")
+        self.stage = stage
+        self.next_topk = cas_config.get("next_topk", None)
+        self.match_type = config["match_type"]
+        assert self.match_type == "softmax"
+        self.temperature = config["dsmax_temperature"]
+        assert div_mode in ("gpu", "cpu")
+        self.recip = div_mode == "gpu"
+
+    def forward(self, feat_c0, feat_c1, idx_c01, idx_c10, data, mask_c0=None, mask_c1=None, heatmap_c0=None, level="4c",
+                pre_level="8c"):
+        if self.training:
+            raise NotImplementedError("CascadeMatching training branch is outside the MI355X hot path")
+        hw0, hw1 = tuple(int(x) for x in data[f"hw0_{level}"]), tuple(int(x) for x in data[f"hw1_{level}"])
+        f0, f1 = feat_c0.contiguous().float(), feat_c1.contiguous().float()
+        idx_c01, idx_c10 = idx_c01.contiguous(), idx_c10.contiguous()
+        d01 = ops.window_match(f0, f1, idx_c01, self.temperature, mask_c0, mask_c1, recip=self.recip, want_conf=True, hw=hw0)
+        d10 = ops.window_match(f1, f0, idx_c10, self.temperature, mask_c1, mask_c0, recip=self.recip, want_conf=False, hw=hw1)
+        data[f"stage_{level}"] = {
+            "conf_matrix": d01["conf_matrix"], "detector_matrix01": None,
+            "next_conf_c01_topk": None, "next_idx_c01_topk": None, "next_conf_c10_topk": None, "next_idx_c10_topk": None,
+            "idx_c01": idx_c01, "idx_c10": idx_c10,
+            "next_idx_c01": d01["next_idx"], "next_idx_c10": d10["next_idx"],
+            "next_conf_c01": d01["next_conf"], "next_conf_c10": d10["next_conf"],
+            "next_conf_c01_s": None, "next_idx_c01_s": None,
+        }
+        match_result = self.get_coarse_match(d01["conf_matrix"], idx_c01, d01["next_conf"], d01["next_idx"], d10["next_idx"],
+                                             data, level, pre_level)
+        data[f"stage_{level}"].update(**match_result)
+        if "m_bids" in match_result:
+            data["m_bids"] = match_result["m_bids"]
+
+    @torch.no_grad()
+    def get_coarse_match(self, conf_matrix01, idx_c01, next_conf_c01, next_idx_c01, next_idx_c10, data, level, pre_level):
+        hw0, hw1 = tuple(int(x) for x in data[f"hw0_{level}"]), tuple(int(x) for x in data[f"hw1_{level}"])
+        if not isinstance(pre_level, list):
+            pre_level = [pre_level]
+        pre = []
+        for i, pl in enumerate(pre_level):
+            pc = data[f"stage_{pl}"]["next_conf_c01"].detach().contiguous().float()
+            pre.append((pc, tuple(int(x) for x in data[f"hw0_{pl}"]), float(self.pre_thr[i])))
+        valid = None
+        if f"mask_{level}0" in data:
+            valid = valid_extents(data[f"mask_{level}0"], data[f"mask_{level}1"])
+        sel = ops.nms_select(next_conf_c01, next_idx_c01, next_idx_c10, hw0, hw1, nms_window=self.post_process.nms_window,
+                             test_thr=float(self.test_thr), pre=pre, border_rm=int(self.border_rm), valid_hw=valid,
+                             double_check=bool(self.double_check))
+        n = int(sel["n"].item())  # host sync, as `mask.sum() == 0` / torch.where in the reference (:254-258)
+        b_ids, i_ids, j_ids, mconf = (sel[k][:n] for k in ("b_ids", "i_ids", "j_ids", "mconf"))
+        w0, w1 = hw0[1], hw1[1]
+        scale = data["hw0_i"][0] / data[f"hw0_{level}"][0]
+        scale0 = scale * data["scale0"][b_ids] if "scale0" in data else scale
+        scale1 = scale * data["scale1"][b_ids] if "scale1" in data else scale
+        mkpts0_c = torch.stack([i_ids % w0, torch.div(i_ids, w0, rounding_mode="trunc")], dim=1) * scale0
+        mkpts1_c = torch.stack([j_ids % w1, torch.div(j_ids, w1, rounding_mode="trunc")], dim=1) * scale1
+        return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "m_bids": b_ids, "mkpts0_c": mkpts0_c,
+                "mkpts1_c": mkpts1_c, "mconf": mconf}

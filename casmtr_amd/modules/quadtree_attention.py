@@ -1,0 +1,224 @@
+"""nn.Module surface of QuadTreeAttention: QTAttB, CascadeQTAttB (+ QTAttGuided, QTAttA for API completeness).
+
+Drop-in for cuda_imp/QuadTreeAttention/QuadtreeAttention/modules/quadtree_attention.py: same constructor arguments,
+same forward signatures, same state-dict keys (`weight`, `get_vs.*`), same return values.
+
+Two execution paths, both on the GPU:
+  * fused (inference, the hot path): one HIP kernel per pyramid level (ops.qta_coarse_level / qta_fine_level /
+    cascade_attn); the [B,L/4,4,K,H] score / softmax / int64-index intermediates of the reference never exist.
+  * composed (autograd, `lepe`, QTAttB `rel_pos`): the reference's op-by-op structure over the HIP primitives
+    score_computation_op / value_aggregation_op, which carry backward kernels.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functions.quadtree_attention import score_computation_op, value_aggregation_op
+
+
+def _tokens(x, nhead):
+    """[B,C,h,w] -> [B,h*w,nhead,C/nhead]  (what :165-167 does with rearrange + view + contiguous)"""
+    B, C, h, w = x.shape
+    return ops.nchw_to_tokens(x.contiguous().float()).view(B, h * w, nhead, C // nhead)
+
+
+def _quad_order(x, h, w):
+    """raster [B,h*w,...] -> quad-major [B,(h/2)*(w/2),4,...]  ("b c h t1 w t2 -> b (h w) (t1 t2) c", :188-189)"""
+    B = x.shape[0]
+    rest = x.shape[2:]
+    x = x.view(B, h // 2, 2, w // 2, 2, *rest)
+    perm = (0, 1, 3, 2, 4) + tuple(range(5, 5 + len(rest)))
+    return x.permute(*perm).reshape(B, (h // 2) * (w // 2), 4, *rest)
+
+
+def _raster_order(x, h, w):
+    """inverse of _quad_order: [B,(h/2)*(w/2),4,...] -> [B,h*w,...]  ("b (h w) (t1 t2) ... -> b (h t1 w t2) ...", :226)"""
+    B = x.shape[0]
+    rest = x.shape[3:]
+    x = x.view(B, h // 2, w // 2, 2, 2, *rest)
+    perm = (0, 1, 3, 2, 4) + tuple(range(5, 5 + len(rest)))
+    return x.permute(*perm).reshape(B, h * w, *rest)
+
+
+def _children(topk_pos, w1, dilated=1):
+    """(row,col) on the coarser grid [2,B,N,K,H] -> child indices on the finer grid [B,N,K,4,H]  (:193-199)"""
+    r, c = topk_pos[0] * 2, topk_pos[1] * 2
+    return torch.stack([(r + x) * w1 + c + y for x in (0, dilated) for y in (0, dilated)], dim=3)
+
+
+def _needs_autograd(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class QTAttB(nn.Module):
+    def __init__(self, nhead, dim, scale, topks=[32, 32, 32, 32], use_dropout=False, attention_dropout=0.1, lepe=False):
+        super().__init__()
+        self.use_dropout = use_dropout
+        self.topks = topks
+        self.nhead = nhead
+        self.dim = dim
+        self.lepe = lepe
+        if lepe:  # locally enhanced position encoding (:151-158)
+            self.get_vs = nn.ModuleList(
+                [nn.Conv2d(dim * nhead, dim * nhead, kernel_size=3, stride=1, padding=1, groups=dim * nhead)
+                 for _ in range(scale)])
+        self.register_parameter("weight", nn.Parameter(torch.randn(scale)))
+
+    # ---- composed path (reference op structure, differentiable) -------------------------------------------------
+    def process_coarse_level(self, query, key, value, topk, rel_pos=None):
+        q, k, v = (_tokens(t, self.nhead) for t in (query, key, value))
+        QK = torch.einsum("nlhd,nshd->nlsh", q, k) * (1.0 / q.shape[-1] ** 0.5)
+        if rel_pos is not None:
+            QK = QK + rel_pos
+        A = torch.softmax(QK, dim=-2)
+        topk_score, topk_idx = torch.topk(A, dim=-2, k=topk, largest=True)
+        message = torch.einsum("nlsh,nshd->nlhd", A, v).contiguous()
+        return A, message, topk_score, topk_idx
+
+    def process_fine_level(self, query, key, value, topk_score, topk_pos, topk_prev, topk, final=False, rel_pos=None):
+        bs, c, h0, w0 = query.shape
+        _, _, h1, w1 = key.shape
+        k, v = _tokens(key, self.nhead), _tokens(value, self.nhead)
+        q = _quad_order(_tokens(query, self.nhead), h0, w0).contiguous()          # [B,L/4,4,H,D]
+        idx = _children(topk_pos, w1).reshape(bs, -1, topk_prev * 4, self.nhead).contiguous()  # parent-major
+        QK = score_computation_op(q, k, idx) * (1.0 / q.shape[-1] ** 0.5)         # [B,L/4,4,4K,H]
+        idx = idx.unsqueeze(2).expand(-1, -1, 4, -1, -1)
+        if rel_pos is not None:  # [1,nhead,L,L] -> gathered at the candidates (:211-215)
+            rp = rel_pos.expand(bs, -1, -1, -1).reshape(bs, self.nhead, h0, w0, h1 * w1).permute(0, 2, 3, 4, 1)
+            rp = _quad_order(rp.reshape(bs, h0 * w0, h1 * w1, self.nhead), h0, w0)
+            QK = QK + torch.gather(rp, index=idx, dim=3)
+        A = torch.softmax(QK, dim=-2)
+        topk_score, topk_i = torch.topk(A, dim=-2, k=topk, largest=True)
+        message = value_aggregation_op(A.contiguous(), v, idx.contiguous())       # [B,L/4,4,H,D]
+        topk_idx = torch.gather(idx, index=topk_i, dim=-2)
+        return A, message, _raster_order(topk_score, h0, w0).contiguous(), _raster_order(topk_idx, h0, w0).contiguous()
+
+    def _forward_composed(self, queries, keys, values, rel_pos):
+        messages = []
+        topk = self.topks[0]
+        topk_score = topk_pos = None
+        for i, (query, key, value) in enumerate(zip(reversed(queries), reversed(keys), reversed(values))):
+            w = key.shape[3]
+            rp = None if rel_pos is None else rel_pos[i]
+            if i == 0:
+                A, message, topk_score, topk_idx = self.process_coarse_level(query, key, value, topk, rel_pos=rp)
+            else:
+                topk_prev, topk = topk, self.topks[i]
+                A, message, topk_score, topk_idx = self.process_fine_level(
+                    query, key, value, topk_score, topk_pos, topk_prev, topk, i == len(queries) - 1, rel_pos=rp)
+            messages.append(message)
+            topk_pos = torch.stack([torch.div(topk_idx, w, rounding_mode="trunc"), topk_idx % w])
+        weight = torch.softmax(self.weight, dim=0)
+        final = None
+        for i, m in enumerate(messages):
+            if self.lepe:
+                lp = _tokens(self.get_vs[i](values[-(i + 1)]), self.nhead)
+                m = m + (lp if i == 0 else _quad_order(lp, *values[-(i + 1)].shape[-2:]))
+            if i == 0:
+                final = m * weight[i]
+            else:
+                hq, wq = queries[-(i + 1)].shape[2:]
+                final = _raster_order(final.unsqueeze(2) + m * weight[i], hq, wq)
+        return final.contiguous()
+
+    # ---- fused path -------------------------------------------------------------------------------------------
+    def _forward_fused(self, queries, keys, values):
+        n = len(queries)
+        weight = torch.softmax(self.weight.detach().float(), dim=0).tolist()  # 3 scalars -> kernel arguments
+        acc = prev_idx = None
+        for i, (query, key, value) in enumerate(zip(reversed(queries), reversed(keys), reversed(values))):
+            B, C, h0, w0 = query.shape
+            h1, w1 = key.shape[2:]
+            q, k, v = (ops.nchw_to_tokens(t.contiguous().float()) for t in (query, key, value))
+            if i == 0:
+                out = ops.qta_coarse_level(q, k, v, self.nhead, self.topks[0], w_level=weight[0], want_message=False)
+            else:
+                # the reference computes top-k at the finest level too and throws it away (:219-227): skipped here
+                topk = self.topks[i] if i < n - 1 else 0
+                out = ops.qta_fine_level(q, k, v, prev_idx, (h0, w0), (h1, w1), self.nhead, topk, w_level=weight[i],
+                                         acc_in=acc, want_message=False)
+            acc, prev_idx = out["acc"], out["topk_idx"]
+        return acc
+
+    def forward(self, queries, keys, values, q_mask=None, kv_mask=None, rel_pos=None):
+        """queries/keys/values: pyramids of [N,C,H,W], finest first -> message [N, H*W, nhead, dim]  (:231-286).
+        q_mask / kv_mask are accepted and ignored, as in the reference."""
+        if self.lepe or rel_pos is not None or _needs_autograd(self.weight, *queries, *keys, *values):
+            return self._forward_composed(queries, keys, values, rel_pos)
+        return self._forward_fused(queries, keys, values)
+
+
+class QTAttGuided(QTAttB):
+    """QTAttB whose first level starts from externally supplied top-k positions (modules/quadtree_attention.py:289-389)."""
+
+    def __init__(self, nhead, dim, scale, topks=[32], use_dropout=False):
+        super().__init__(nhead, dim, scale, topks=topks, use_dropout=use_dropout)
+
+    def forward(self, queries, keys, values, q_mask=None, kv_mask=None, rel_pos=None, topk_pos=None):
+        messages = []
+        topk = self.topks[0]
+        for i, (query, key, value) in enumerate(zip(reversed(queries), reversed(keys), reversed(values))):
+            w = key.shape[3]
+            rp = None if rel_pos is None else rel_pos[i]
+            topk_prev, topk = topk, self.topks[i]
+            _, message, _, topk_idx = self.process_fine_level(query, key, value, None, topk_pos, topk_prev, topk,
+                                                              i == len(queries) - 1, rel_pos=rp)
+            messages.append(message)
+            topk_pos = torch.stack([torch.div(topk_idx, w, rounding_mode="trunc"), topk_idx % w])
+        weight = torch.softmax(self.weight, dim=0)
+        final = None
+        for i, m in enumerate(messages):
+            final = m * weight[i] if i == 0 else final.unsqueeze(2) + m * weight[i]
+            hq, wq = queries[-(i + 1)].shape[2:]
+            final = _raster_order(final, hq, wq)
+        return final.contiguous()
+
+
+class QTAttA(nn.Module):
+    """Variant A (modules/quadtree_attention.py:8-140).  No shipped config selects it (`attn_type='B'`, SURVEY.md §8
+    a13 / §8(f)-4); the name exists so that `from ... import QTAttA, QTAttB, CascadeQTAttB, QTAttGuided`
+    (src/model/modules/quadtree_attention.py:6) keeps working.  Constructing it fails loudly instead of silently
+    computing something else."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("QTAttA is not part of the MI355X hot path (no shipped CasMTR config uses attn_type='A')")
+
+
+class CascadeQTAttB(nn.Module):
+    def __init__(self, nhead, dim, dilated, use_dropout=False):
+        super().__init__()
+        self.use_dropout = use_dropout
+        self.nhead = nhead
+        self.dim = dim
+        self.dilated = 1 if dilated is None else dilated
+
+    def _forward_composed(self, query, key, value, topk_pos, rel_pos):
+        bs, c, h0, w0 = query.shape
+        _, _, h1, w1 = key.shape
+        kw = topk_pos.shape[2]
+        k, v = _tokens(key, self.nhead), _tokens(value, self.nhead)
+        q = _quad_order(_tokens(query, self.nhead), h0, w0).contiguous()
+        pos = topk_pos.permute(3, 0, 1, 2).unsqueeze(-1).expand(-1, -1, -1, -1, self.nhead)  # [2,B,L/4,KW,H]
+        idx = torch.clamp(_children(pos, w1, self.dilated), min=0, max=h1 * w1 - 1)
+        idx = idx.reshape(bs, -1, kw * 4, self.nhead).contiguous()
+        QK = score_computation_op(q, k, idx) * (1.0 / q.shape[-1] ** 0.5)
+        if rel_pos is not None:
+            rp = rel_pos.view(bs, self.nhead, h0 * w0, kw * 4).permute(0, 2, 3, 1)
+            QK = QK + _quad_order(rp, h0, w0)
+        A = torch.softmax(QK, dim=-2)
+        idx5 = idx.unsqueeze(2).expand(-1, -1, 4, -1, -1).contiguous()
+        message = value_aggregation_op(A.contiguous(), v, idx5)
+        message = _raster_order(message, h0, w0).reshape(bs, h0 * w0, c)
+        return message, _raster_order(idx5[..., 0], h0, w0)
+
+    def forward(self, query, key, value, topk_pos, rel_pos):
+        """query/key/value [N,C,H,W]; topk_pos [N,(H/2)(W/2),KW,2] (row,col) -> message [N,HW,C], upsampled_idx
+        [N,HW,4*KW]  (modules/quadtree_attention.py:400-452)."""
+        if _needs_autograd(query, key, value, rel_pos):
+            return self._forward_composed(query, key, value, topk_pos, rel_pos)
+        h0, w0 = query.shape[2:]
+        h1, w1 = key.shape[2:]
+        q, k, v = (ops.nchw_to_tokens(t.contiguous().float()) for t in (query, key, value))
+        rp = None if rel_pos is None else rel_pos.contiguous().float()
+        return ops.cascade_attn(q, k, v, topk_pos.contiguous(), (h0, w0), (h1, w1), self.nhead, self.dilated, rp)

@@ -132,6 +132,21 @@ int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* next_idx01, c
                           int B, int H0, int W0, int H1, int W1, casmtr_stream_t stream);
 size_t casmtr_nms_select_ws_bytes(int B, int H0, int W0);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart): per-kernel launch durations from HIP events recorded on the
+ * launch stream.  Off by default.  casmtr_prof_enable(1) starts a fresh collection; casmtr_prof_read() waits for
+ * the recorded events and returns the summed duration (ms) and the number of launches of kernel `id`.
+ * ---------------------------------------------------------------------------------------------------------- */
+enum {
+    CASMTR_PROF_DS_GEMM = 0, CASMTR_PROF_DS_REDUCE, CASMTR_PROF_DS_CONF, CASMTR_PROF_DS_SELECT,
+    CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
+    CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
+    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_COUNT
+};
+void casmtr_prof_enable(int on);
+int casmtr_prof_read(int id, double* total_ms, int* count);
+const char* casmtr_prof_name(int id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,194 @@
+"""GPU: the module surface (QTAttB / CascadeQTAttB / CoarseMatching / CascadeMatching) against the reference-python
+fixtures, and the whole hot-path chain at the BASELINE size against the oracle / size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_inputs import CASES, make_inputs
+from parity_utils import assert_close, load_golden, match_set
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", list(CASES["qtattb"]))
+def test_qtattb_module_vs_reference(name):
+    from casmtr_amd.modules.quadtree_attention import QTAttB
+    inp = make_inputs("qtattb", name)
+    cfg = CASES["qtattb"][name]
+    g = load_golden("qtattb", name)
+    m = QTAttB(cfg["nhead"], cfg["D"], scale=3, topks=cfg["topks"]).to(DEV).eval()
+    with torch.no_grad():
+        m.weight.copy_(T(inp["weight"]))
+        out = m([T(x) for x in inp["queries"]], [T(x) for x in inp["keys"]], [T(x) for x in inp["values"]])
+    assert out.shape == g["final"].shape
+    assert_close(N(out), g["final"], TOL, "QTAttB fused forward vs reference python")
+    # the differentiable composed path (primitives + torch) must agree with the fused one
+    qs = [T(x).requires_grad_(True) for x in inp["queries"]]
+    out2 = m(qs, [T(x) for x in inp["keys"]], [T(x) for x in inp["values"]])
+    assert_close(N(out2), g["final"], TOL, "QTAttB composed forward vs reference python")
+    out2.sum().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in qs)
+    assert m.weight.grad is not None
+
+
+@pytest.mark.parametrize("name", list(CASES["cascade_attn"]))
+def test_cascade_module_vs_reference(name):
+    from casmtr_amd.modules.quadtree_attention import CascadeQTAttB
+    inp = make_inputs("cascade_attn", name)
+    cfg = CASES["cascade_attn"][name]
+    g = load_golden("cascade_attn", name)
+    m = CascadeQTAttB(cfg["nhead"], cfg["D"], dilated=1).to(DEV)
+    tp = T(g["topk_pos"].astype(np.int64))
+    rel = T(inp["rel_pos"]) if cfg.get("rel_pos") else None
+    with torch.no_grad():
+        msg, up = m(T(inp["q"]), T(inp["k"]), T(inp["v"]), tp, rel)
+    assert np.array_equal(N(up), g["upsampled_idx"].astype(np.int64))
+    assert_close(N(msg), g["message"], TOL, "fused")
+    q = T(inp["q"]).requires_grad_(True)
+    msg2, up2 = m(q, T(inp["k"]), T(inp["v"]), tp, rel)
+    assert np.array_equal(N(up2), g["upsampled_idx"].astype(np.int64))
+    assert_close(N(msg2), g["message"], TOL, "composed")
+    msg2.square().sum().backward()
+    assert torch.isfinite(q.grad).all()
+
+
+@pytest.mark.parametrize("name", list(CASES["coarse_matching"]))
+def test_coarse_matching_module(name):
+    from casmtr_amd.matching.coarse_matching import CoarseMatching
+    inp = make_inputs("coarse_matching", name)
+    cfg = CASES["coarse_matching"][name]
+    g = load_golden("coarse_matching", name)
+    mc = {"thr": cfg.get("thr", 0.2), "border_rm": cfg.get("border_rm", 0), "train_coarse_percent": 0.3,
+          "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.get("T", 0.1)}
+    cm = CoarseMatching(mc, div_mode="cpu").eval()   # fixtures come from the reference on CPU
+    h0, w0 = cfg["hw0"]
+    h1, w1 = cfg["hw1"]
+    data = {"hw0_i": (h0 * 8, w0 * 8), "hw1_i": (h1 * 8, w1 * 8), "hw0_8c": (h0, w0), "hw1_8c": (h1, w1)}
+    m0 = m1 = None
+    if cfg.get("masks"):
+        data["mask_8c0"], data["mask_8c1"] = T(inp["mask0"]).bool(), T(inp["mask1"]).bool()
+        m0, m1 = data["mask_8c0"].flatten(-2), data["mask_8c1"].flatten(-2)
+    with torch.no_grad():
+        cm(T(inp["feat0"]), T(inp["feat1"]), data, mask_c0=m0, mask_c1=m1, level="8c")
+    st = data["stage_8c"]
+    assert (N(st["next_idx_c01"]) != g["next_idx_c01"]).mean() <= 1e-3
+    assert (N(st["next_idx_c10"]) != g["next_idx_c10"]).mean() <= 1e-3
+    assert_close(N(st["next_conf_c01"]), g["next_conf_c01"], TOL, "next_conf_c01")
+    if "conf_matrix" in g:
+        assert_close(N(st["conf_matrix"]), g["conf_matrix"], TOL, "conf_matrix")
+    got, want = match_set(N(st["b_ids"]), N(st["i_ids"]), N(st["j_ids"])), match_set(g["b_ids"], g["i_ids"], g["j_ids"])
+    assert len(got ^ want) <= 1
+    if got == want:
+        assert_close(N(st["mkpts0_c"]), g["mkpts0_c"], 1e-6, "mkpts0_c")
+        assert_close(N(st["mkpts1_c"]), g["mkpts1_c"], 1e-6, "mkpts1_c")
+        assert_close(N(st["mconf"]), g["mconf"], TOL, "mconf")
+
+
+@pytest.mark.parametrize("name", list(CASES["cascade_matching"]))
+def test_cascade_matching_module(name):
+    from casmtr_amd.matching.cascade_matching import CascadeMatching
+    inp = make_inputs("cascade_matching", name)
+    cfg = CASES["cascade_matching"][name]
+    g = load_golden("cascade_matching", name)
+    hc, wc = cfg["coarse_hw"]
+    h, w = 2 * hc, 2 * wc
+    mcfg = {"thr": 0.2, "test_thr": cfg.get("test_thr", 0.2), "pre_thr": [cfg.get("pre_thr", 0.2)],
+            "border_rm": cfg.get("border_rm", 2), "double_check": cfg.get("double_check", True),
+            "train_pad_num_gt_min": 200, "match_type": "softmax", "dsmax_temperature": 1.0}
+    post = {"method": "maxpool_nms", "window_size": 5} if cfg.get("nms", True) else {"method": None}
+    cm = CascadeMatching(mcfg, {"propagation": "window", "dilated": 1, "post_config": post}, stage="4c", div_mode="cpu").eval()
+    data = {"hw0_i": (h * 4, w * 4), "hw1_i": (h * 4, w * 4), "hw0_8c": (hc, wc), "hw1_8c": (hc, wc), "hw0_4c": (h, w),
+            "hw1_4c": (h, w), "stage_8c": {"next_conf_c01": T(inp["pre_conf"])}}
+    m0 = m1 = None
+    if cfg.get("masks"):
+        data["mask_4c0"], data["mask_4c1"] = T(inp["mask0"]).bool(), T(inp["mask1"]).bool()
+        m0, m1 = data["mask_4c0"].flatten(-2), data["mask_4c1"].flatten(-2)
+    with torch.no_grad():
+        cm(T(inp["feat0"]), T(inp["feat1"]), T(g["idx_c01"].astype(np.int64)), T(g["idx_c10"].astype(np.int64)), data,
+           mask_c0=m0, mask_c1=m1, level="4c", pre_level="8c")
+    st = data["stage_4c"]
+    assert_close(N(st["conf_matrix"]), g["conf_matrix"], TOL, "conf_matrix01")
+    assert_close(N(st["next_conf_c01"]), g["next_conf_c01"], TOL, "next_conf_c01")
+    assert (N(st["next_idx_c01"]) != g["next_idx_c01"]).mean() <= 2e-3
+    got, want = match_set(N(st["b_ids"]), N(st["i_ids"]), N(st["j_ids"])), match_set(g["b_ids"], g["i_ids"], g["j_ids"])
+    # selection thresholds act on softmax values that differ by ulps between CPU and GPU expf -> borderline only
+    assert len(got ^ want) <= max(1, len(want) // 100), (len(got), len(want))
+    assert "m_bids" in data
+
+
+def test_compat_reference_names_on_gpu():
+    import casmtr_amd.compat as compat
+    compat.install()
+    import fast_score_computation
+    import score_computation_cuda
+    import value_aggregation_cuda
+    inp = make_inputs("ops", "k64_h8")
+    s = score_computation_cuda.score_forward(T(inp["q"]), T(inp["key"]), T(inp["idx"]))
+    assert isinstance(s, list) and np.array_equal(N(s[0]), oracle.qta_score_fwd(inp["q"], inp["key"], inp["idx"]))
+    w = fast_score_computation.score_forward(T(inp["wq"]), T(inp["wkey"]), T(inp["widx"]))
+    assert np.array_equal(N(w[0]), oracle.window_score_fwd(inp["wq"], inp["wkey"], inp["widx"]))
+    A = torch.rand(s[0].shape, device=DEV)
+    B, N1, _, K, H = A.shape
+    out = torch.zeros((B, N1 * 4, H, 32), device=DEV)
+    idx5 = T(np.repeat(inp["idx"][:, :, None], 4, axis=2).reshape(B, N1 * 4, K, H))
+    assert value_aggregation_cuda.value_aggregation_forward(A.view(B, N1 * 4, K, H), T(inp["value"]), idx5, out) is None
+    assert out.abs().sum() > 0
+
+
+@pytest.mark.parametrize("B", [1])
+def test_full_size_chain_vs_oracle(B):
+    """BASELINE configs[1] shapes (CasMTR-4c, 832x832): every index output of the chain bit-matches the oracle."""
+    from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
+    cfg = HotPathConfig()
+    model = HotPath(cfg).to(DEV)
+    inp = make_synthetic_inputs(cfg, B, DEV, seed=7)
+    with torch.no_grad():
+        model.qta.weight.copy_(inp["weight"])
+        out = model(inp)
+    torch.cuda.synchronize()
+    d = out["data"]
+    n = lambda t: N(t[:1])
+    # QTAttB: one cross call at the full 104x104 grid
+    fo, lv = oracle.qtattb_forward([n(x) for x in inp["cq0"]], [n(x) for x in inp["ck1"]], [n(x) for x in inp["cv1"]],
+                                   N(inp["weight"]), cfg.coarse_heads, cfg.coarse_topks)
+    assert_close(N(out["messages"][2][:1]), fo, TOL, "QTAttB cross message (104x104)")
+    # coarse matching
+    o8 = oracle.dual_softmax(n(inp["feat_8c0"]), n(inp["feat_8c1"]), cfg.hw8, cfg.hw8, cfg.coarse_temperature, cfg.coarse_thr,
+                             cfg.coarse_border_rm, recip=True)
+    st8 = d["stage_8c"]
+    assert np.array_equal(N(st8["next_idx_c01"][:1]), o8["next_idx_c01"]), "coarse row argmax (10816 x 10816)"
+    assert np.array_equal(N(st8["next_idx_c10"][:1]), o8["next_idx_c10"]), "coarse column argmax"
+    assert_close(N(st8["next_conf_c01"][:1]), o8["next_conf_c01"], TOL, "coarse next_conf")
+    sel = N(st8["b_ids"]) == 0
+    got = match_set(N(st8["b_ids"])[sel], N(st8["i_ids"])[sel], N(st8["j_ids"])[sel])
+    want = match_set(o8["b_ids"], o8["i_ids"], o8["j_ids"])
+    assert len(got ^ want) <= max(1, len(want) // 1000) and len(want) > 1000
+    # cascade attention + matching
+    tp01 = oracle.window_warp_idx(o8["next_idx_c01"], *cfg.hw8, cfg.window_size)
+    tok = lambda x: np.ascontiguousarray(n(x).transpose(0, 2, 3, 1).reshape(1, -1, cfg.cascade_dim))
+    mo, i01 = oracle.cascade_attn(tok(inp["fq0"]), tok(inp["fk1"]), tok(inp["fv1"]), tp01, cfg.hw4, cfg.hw4, cfg.cascade_heads)
+    st4 = d["stage_4c"]
+    assert np.array_equal(N(st4["idx_c01"][:1]), i01), "upsampled window indices"
+    assert_close(N(out["messages"][12][:1]), mo, TOL, "CascadeQTAttB message (208x208)")
+    m01 = oracle.window_match(n(inp["feat_4c0"]), n(inp["feat_4c1"]), i01, cfg.cascade_temperature, recip=True)
+    assert np.array_equal(N(st4["next_idx_c01"][:1]), m01["next_idx"]), "cascade argmax (43264 x 100)"
+    assert_close(N(st4["conf_matrix"][:1]), m01["conf_matrix"], TOL, "cascade conf_matrix")
+    assert out["mconf"].numel() > 100
+    # size-independent properties: every kept match survives its own definition
+    i_ids, j_ids, b_ids = N(st4["i_ids"]), N(st4["j_ids"]), N(st4["b_ids"])
+    ni01, ni10, nc01 = N(st4["next_idx_c01"]), N(st4["next_idx_c10"]), N(st4["next_conf_c01"])
+    assert np.array_equal(ni01[b_ids, i_ids], j_ids)
+    assert np.array_equal(ni10[b_ids, j_ids], i_ids), "double check"
+    assert (nc01[b_ids, i_ids] > cfg.cascade_test_thr).all()
+    assert (np.diff(b_ids * 10**6 + i_ids) > 0).all(), "(b,i) ordering"
