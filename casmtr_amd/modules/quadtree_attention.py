@@ -19,6 +19,8 @@ from ..functions.quadtree_attention import score_computation_op, value_aggregati
 def _tokens(x, nhead):
     """[B,C,h,w] -> [B,h*w,nhead,C/nhead]  (what :165-167 does with rearrange + view + contiguous)"""
     B, C, h, w = x.shape
+    if torch.is_grad_enabled() and x.requires_grad:  # differentiable layout change for the composed path
+        return x.float().permute(0, 2, 3, 1).reshape(B, h * w, nhead, C // nhead).contiguous()
     return ops.nchw_to_tokens(x.contiguous().float()).view(B, h * w, nhead, C // nhead)
 
 
