@@ -1,0 +1,70 @@
+"""CPU: the N>1 path (sharding, parameter broadcast, gatherv of matches) with world_size 2 over gloo."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from casmtr_amd import dist as cdist
+    r, w, _ = cdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and cdist.is_dist()
+    # start-up broadcast of the parameter buffer
+    m = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.fill_(float(rank + 1))
+    cdist.broadcast_parameters(m)
+    assert all(torch.all(p == 1.0) for p in m.parameters())
+    # shard 5 pairs over 2 ranks: contiguous blocks covering everything exactly once
+    lo, hi = cdist.shard_range(5, rank, world)
+    # ragged gather, including an empty rank
+    M = 0 if rank == 1 else 4
+    out = {"m_bids": torch.arange(M) % 2, "mkpts0": torch.full((M, 2), float(rank)), "mkpts1": torch.full((M, 2), 7.0),
+           "mconf": torch.linspace(0, 1, M) if M else torch.zeros(0)}
+    res = cdist.gather_matches(out, pairs_per_rank=2)
+    t = cdist.max_over_ranks(float(rank))
+    cdist.barrier()
+    if rank == 0:
+        q.put(dict(range=(lo, hi), n=res["n_total"], counts=res["counts"], bids=res["m_bids"].tolist(), shape=tuple(res["mk"].shape), tmax=t))
+    else:
+        assert res is None
+        q.put(dict(range=(lo, hi)))
+    cdist.finalize()
+
+
+def test_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ranges = sorted(o["range"] for o in outs)
+    assert ranges == [(0, 3), (3, 5)]
+    r0 = next(o for o in outs if "n" in o)
+    assert r0["n"] == 4 and r0["counts"] == [4, 0] and r0["shape"] == (4, 5) and r0["bids"] == [0, 1, 0, 1] and r0["tmax"] == 1.0
+
+
+def test_single_process_passthrough():
+    from casmtr_amd import dist as cdist
+    assert not cdist.is_dist() and cdist.max_over_ranks(2.5) == 2.5
+    out = {"m_bids": torch.zeros(3, dtype=torch.long), "mkpts0": torch.ones(3, 2), "mkpts1": torch.ones(3, 2), "mconf": torch.ones(3)}
+    res = cdist.gather_matches(out)
+    assert res["n_total"] == 3 and res["mk"].shape == (3, 5)
+    assert cdist.shard_range(32, 3, 8) == (12, 16)
