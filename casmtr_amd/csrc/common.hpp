@@ -48,18 +48,21 @@ __device__ __forceinline__ float row16_sum_f32(float v) {
     return v;
 }
 
-// Whole-wave (64 lane) reductions, result valid in every lane.
+// Whole-wave (64 lane) reductions, wave-uniform result (SGPR): DPP inside each 16-lane row, then one v_readlane per
+// row and scalar combines -- no ds_bpermute / LDS round trip on the dependent chain.
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = row16_max_u32(v);
-    v = max(v, (unsigned)__shfl_xor((int)v, 16));
-    v = max(v, (unsigned)__shfl_xor((int)v, 32));
-    return v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ float wave_sum_f32(float v) {
     v = row16_sum_f32(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    const float a = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+    const float b = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    const float c = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    const float d = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
+    return (a + b) + (c + d);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
     return ord2f(wave_max_u32(f2ord(v)));
@@ -68,6 +71,44 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 __device__ __forceinline__ float div_scalar(float x, float s, float inv_s, int recip) {
     // torch CPU: true fp32 division; torch GPU kernels: x * fl32(1/s)  (see oracle/casmtr_oracle.c header)
     return recip ? __fmul_rn(x, inv_s) : __fdiv_rn(x, s);
+}
+
+// Wave-private transposition through LDS: 64 rows x 32 floats (128 B = one cache line each).  Global side: 8 lanes
+// share a row (one dwordx4 each), so every load instruction covers 8 whole lines (coalesced; a lane-per-row walk
+// touches 64 lines per instruction and runs at a quarter of the L1/TA rate).  LDS side: rows padded to 36 floats ->
+// the ds_write_b128 (8-lane groups = one row) and the ds_read_b128 (lane l reads row l) are both conflict-free.
+// row_ptr(r) returns the global address of row r (0..63) and must be valid for every r.
+#define CASMTR_SLAB_FLOATS (64 * 36)
+template <typename RowPtr>
+__device__ __forceinline__ void wave_rows32_to_lanes(float* slab, int lane, RowPtr row_ptr, f32x4 (&out)[8]) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(row_ptr(8 * j + (lane >> 3)) + (lane & 7) * 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(slab + (8 * j + (lane >> 3)) * 36 + (lane & 7) * 4) = v[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const f32x4*>(slab + lane * 36 + i * 4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Bijective "XCD-contiguous" remap of a 1-D block id: the dispatcher is observed to place block b on XCD b % 8; this
+// gives each XCD one contiguous chunk of the logical index space so that neighbouring tiles share an L2.  Speed only.
+__device__ __forceinline__ int xcd_chunk_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// Read-only, wave-uniform operands (a query row shared by the whole wave): viewing the pointer in the constant
+// address space tells the compiler the data is invariant for the kernel, so it emits s_load_dwordxN (scalar cache,
+// SGPR operands for v_fmac) even inside loops that also store to other buffers.  Only for data written by EARLIER kernels.
+typedef const float __attribute__((address_space(4))) * cfloat_p;
+__device__ __forceinline__ cfloat_p as_const(const float* p) {
+    return (cfloat_p)(unsigned long long)p;
 }
 
 // prof.hip

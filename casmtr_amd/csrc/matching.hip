@@ -77,13 +77,13 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_kernel(const float* __restrict
     const int lrow = tid >> 1, lc0 = (tid & 1) * 16;
     const float* ap = f0 + ((size_t)b * L + (i0 + lrow < L ? i0 + lrow : L - 1)) * C + lc0;
     const float* bp = f1 + ((size_t)b * S + (j0 + lrow < S ? j0 + lrow : S - 1)) * C + lc0;
-    for (int k0 = 0; k0 < C; k0 += DS_BK) {
-        f32x4 av[4], bv[4];
+    f32x4 av[4], bv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            av[i] = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * i);
-            bv[i] = *reinterpret_cast<const f32x4*>(bp + k0 + 4 * i);
-        }
+    for (int i = 0; i < 4; ++i) {
+        av[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+        bv[i] = *reinterpret_cast<const f32x4*>(bp + 4 * i);
+    }
+    for (int k0 = 0; k0 < C; k0 += DS_BK) {
         __syncthreads();  // previous k-tile fully consumed
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_kernel(const float* __restrict
                 As[lrow][lc0 + 4 * i + c] = div_scalar(av[i][c], sqrtC, inv_sqrtC, recip);
                 Bs[lrow][lc0 + 4 * i + c] = div_scalar(bv[i][c], sqrtC, inv_sqrtC, recip);
             }
+        if (k0 + DS_BK < C) {  // prefetch the next k-tile into registers; it lands while the MFMAs below run
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = *reinterpret_cast<const f32x4*>(ap + k0 + DS_BK + 4 * i);
+                bv[i] = *reinterpret_cast<const f32x4*>(bp + k0 + DS_BK + 4 * i);
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < DS_BK / 2; ++kk) {
@@ -180,43 +187,82 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
 
 // Pass 2: conf = softmax10 * softmax01 (coarse_matching.py:66-68), best-of-row / best-of-column (value, first index)
 // through packed 64-bit atomicMax; optionally overwrites sim with conf (the reference's data['stage_8c']['conf_matrix']).
+// Streaming kernel: a wave owns 256 consecutive columns (one float4 per lane) of a 64-row strip; row statistics come in
+// through wave-uniform scalar loads, the column best lives in registers, the row best is a DPP wave reduction -> one
+// atomic per (row, wave).  No LDS, full occupancy, 1 KiB coalesced reads.
+#define DSC_ROWS 64
 __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // tile[64][257], rm[64], rs[64]
-    float (*tile)[257] = reinterpret_cast<float (*)[257]>(smem);
-    float* rm = smem + 64 * 257;
-    float* rs = rm + 64;
-    const int b = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 256;
-    const int tid = threadIdx.x;
-    const int nr = min(64, L - i0), nc = min(256, S - j0);
-    if (tid < 64 && tid < nr) {
-        rm[tid] = w.rmax[(size_t)b * L + i0 + tid];
-        rs[tid] = w.rsum[(size_t)b * L + i0 + tid];
+    const int b = blockIdx.z, i0 = blockIdx.y * DSC_ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = blockIdx.x * 1024 + wave * 256 + lane * 4;
+    if (blockIdx.x * 1024 + wave * 256 >= S) return;
+    const bool vec = (S & 3) == 0 && j + 3 < S;
+    const int nr = min(DSC_ROWS, L - i0);
+    float cm[4], cinv[4], best[4];
+    int bi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int jj = min(j + u, S - 1);
+        cm[u] = w.cmax[(size_t)b * S + jj];
+        cinv[u] = 1.0f / w.csum[(size_t)b * S + jj];
+        best[u] = -1.f; bi[u] = 0;
     }
-    __syncthreads();
-    if (tid < nc) {
-        const int gj = j0 + tid;
-        const float cm = w.cmax[(size_t)b * S + gj], cs = w.csum[(size_t)b * S + gj];
-        float best = -1.f; int bi = 0;
-        float* col = sim + ((size_t)b * L + i0) * S + gj;
-        for (int r = 0; r < nr; ++r) {
-            const float x = col[(size_t)r * S];
-            const float p01 = expf(x - rm[r]) / rs[r];
-            const float p10 = expf(x - cm) / cs;
-            const float cf = p10 * p01;
-            tile[r][tid] = cf;
-            if (want_conf) col[(size_t)r * S] = cf;
-            if (cf > best) { best = cf; bi = i0 + r; }
+    const float* rmax = w.rmax + (size_t)b * L + i0;   // wave-uniform
+    const float* rsum = w.rsum + (size_t)b * L + i0;
+    float* base = sim + ((size_t)b * L + i0) * S + j;
+    constexpr int RU = 4;  // rows in flight per lane
+    for (int r0 = 0; r0 < nr; r0 += RU) {
+        float x[RU][4];
+#pragma unroll
+        for (int q = 0; q < RU; ++q) {
+            const int r = min(r0 + q, nr - 1);
+            if (vec) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)r * S);
+                x[q][0] = t.x; x[q][1] = t.y; x[q][2] = t.z; x[q][3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[q][u] = (j + u < S) ? base[(size_t)r * S + u] : 0.f;
+            }
         }
-        const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (0xFFFFFFFFu - (unsigned)bi);
-        atomicMax(w.cbest + (size_t)b * S + gj, key);
+#pragma unroll
+        for (int q = 0; q < RU; ++q) {
+            const int r = r0 + q;
+            if (r >= nr) break;  // wave-uniform
+            const float rm = rmax[r], rinv = 1.0f / rsum[r];
+            float cf[4];
+            float rbest = -1.f; int rj = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float p01 = expf(x[q][u] - rm) * rinv;
+                const float p10 = expf(x[q][u] - cm[u]) * cinv[u];
+                cf[u] = (j + u < S) ? p10 * p01 : -1.f;
+                if (cf[u] > best[u]) { best[u] = cf[u]; bi[u] = i0 + r; }
+                if (cf[u] > rbest) { rbest = cf[u]; rj = j + u; }
+            }
+            if (want_conf) {
+                if (vec) *reinterpret_cast<f32x4*>(base + (size_t)r * S) = (f32x4){cf[0], cf[1], cf[2], cf[3]};
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (j + u < S) base[(size_t)r * S + u] = cf[u];
+                }
+            }
+            // row best over the wave's 256 columns: max value, then the first lane holding it (lanes are column-ordered)
+            const unsigned kb = rbest >= 0.f ? __float_as_uint(rbest) : 0u;
+            const unsigned wm = wave_max_u32(kb);
+            const unsigned long long bal = __ballot(kb == wm && rbest >= 0.f);
+            if (bal && lane == __ffsll((long long)bal) - 1) {
+                const unsigned long long key = ((unsigned long long)wm << 32) | (0xFFFFFFFFu - (unsigned)rj);
+                atomicMax(w.rbest + (size_t)b * L + i0 + r, key);
+            }
+        }
     }
-    __syncthreads();
-    if (tid < nr) {
-        float best = -1.f; int bj = 0;
-        for (int c = 0; c < nc; ++c) { const float cf = tile[tid][c]; if (cf > best) { best = cf; bj = j0 + c; } }
-        const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (0xFFFFFFFFu - (unsigned)bj);
-        atomicMax(w.rbest + (size_t)b * L + i0 + tid, key);
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (j + u < S && best[u] >= 0.f) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best[u]) << 32) | (0xFFFFFFFFu - (unsigned)bi[u]);
+            atomicMax(w.cbest + (size_t)b * S + j + u, key);
+        }
 }
 
 // coarse_matching.py:116-132: conf > thr, border removal, mutual maximum BY VALUE, first j per row.
@@ -346,10 +392,9 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C);
     static bool attr_set = false;
-    const size_t gemm_lds = sizeof(float) * 128 * 129, conf_lds = sizeof(float) * (64 * 257 + 128);
+    const size_t gemm_lds = sizeof(float) * 128 * 129;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_conf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conf_lds);
         attr_set = true;
     }
     {
@@ -372,8 +417,8 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     if (e != hipSuccess) return (int)e;
     {
         ProfScope ps(CASMTR_PROF_DS_CONF, s);
-        hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 255) / 256, (L + 63) / 64, B), dim3(256), conf_lds, s, sim_ws, w, L, S,
-                           want_conf);
+        hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
+                           w, L, S, want_conf);
     }
     CASMTR_CHECK_LAUNCH();
     ProfScope ps(CASMTR_PROF_DS_SELECT, s);
@@ -384,133 +429,102 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
 }
 
 // =================================================================================================== window match
-// One workgroup per quad of query tokens (4 children of a coarse cell) when (h,w) is given: their K window rows are
-// the same list (CascadeQTAttB's upsampled_idx, modules/quadtree_attention.py:450), so the K x C key tile is
-// normalised and staged in LDS once and scored by 4 waves (wave <-> child token, lane <-> candidate).  If the 4 index
-// rows differ (generic caller) the tile is restaged per token -- same results, more traffic.
+// One wave per query token, 4 tokens per workgroup, no block-level synchronisation.  The C channels are walked in
+// chunks of 32 (one 128-B line per candidate row): each chunk of the K candidate rows goes through the wave's slab
+// (coalesced loads, wave_rows32_to_lanes), every lane normalises its own row chunk and extends its fmaf chain
+// (c ascending across chunks, so the result is the reference's sequential chain).  The query chunk comes in through
+// wave-uniform scalar loads.  lane <-> candidates k = lane and 64 + lane (K <= 128).
 template <int C>
 __global__ __launch_bounds__(256) void window_match_kernel(const float* __restrict__ fq, const float* __restrict__ fk,
                                                            const int64_t* __restrict__ idx,
                                                            const uint8_t* __restrict__ mq, const uint8_t* __restrict__ mk,
                                                            float sqrtC, float inv_sqrtC, float T, float invT, int recip,
                                                            float* __restrict__ conf, float* __restrict__ next_conf,
-                                                           int64_t* __restrict__ next_idx, int N, int M, int K, int h,
-                                                           int w) {
-    constexpr int CP = C + 4;   // padded row (floats): conflict-free ds_read_b128 across lanes
-    constexpr int KMAXW = 128;
+                                                           int64_t* __restrict__ next_idx, int N, int M, int K,
+                                                           int nblocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* rows = smem;                                   // [KMAXW][CP]
-    int* cidx = reinterpret_cast<int*>(smem + KMAXW * CP);  // [4][KMAXW]
-    int& differ = cidx[4 * KMAXW];                          // all LDS in the dynamic region (keeps it 16-B aligned)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* slab = smem + wave * (CASMTR_SLAB_FLOATS + 128);
+    int* cand = reinterpret_cast<int*>(slab + CASMTR_SLAB_FLOATS);  // [128]
     const int b = blockIdx.y;
-    int tok[4];
-    if (h > 0) {
-        const int wq = w >> 1, qy = blockIdx.x / wq, qx = blockIdx.x % wq;
+    const int n = xcd_chunk_remap(blockIdx.x, nblocks) * 4 + wave;   // neighbouring tokens (overlapping windows) share an L2
+    if (n >= N) return;
+    const int64_t* ip = idx + ((size_t)b * N + n) * K;
+    const int c0 = lane < K ? (int)ip[lane] : 0;
+    const int c1 = 64 + lane < K ? (int)ip[64 + lane] : 0;
+    cand[lane] = c0;
+    cand[64 + lane] = c1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const cfloat_p qp = as_const(fq + ((size_t)b * N + n) * C);  // wave-uniform -> scalar loads
+    const float* kb = fk + (size_t)b * M * C;
+    float acc[2] = {0.f, 0.f};
+    // (a register double-buffered version of this loop -- loads of step s+1 issued before step s is consumed -- was
+    //  measured 3x SLOWER: it spills at the 4-waves/SIMD budget and occupancy, not prefetch depth, is what hides latency here)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) tok[f] = (2 * qy + (f >> 1)) * w + 2 * qx + (f & 1);
-    } else {
+    for (int ch = 0; ch < C / 32; ++ch) {
+        float qn[32];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) tok[f] = blockIdx.x * 4 + f;
-    }
-    if (tid == 0) differ = 0;
-    __syncthreads();
-    for (int e = tid; e < 4 * K; e += 256) {
-        const int f = e / K, k = e % K;
-        cidx[f * KMAXW + k] = tok[f] < N ? (int)idx[((size_t)b * N + tok[f]) * K + k] : 0;
-    }
-    __syncthreads();
-    {
-        bool d = false;
-        for (int e = tid; e < 4 * K; e += 256) {
-            const int f = e / K, k = e % K;
-            if (tok[f] < N && cidx[f * KMAXW + k] != cidx[k]) d = true;
-        }
-        if (d) differ = 1;
-    }
-    __syncthreads();
-    const bool shared_rows = (differ == 0);
-    const int n = tok[wave];
-    const int rounds = shared_rows ? 1 : 4;
-    for (int rd = 0; rd < rounds; ++rd) {
-        if (rd > 0) __syncthreads();
-        {   // stage + normalise the K rows of token `rd`'s list (== everyone's list when shared)
-            const int c4 = (tid % (C / 4)) * 4;
-            for (int r = tid / (C / 4); r < K; r += 256 / (C / 4)) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(fk + ((size_t)b * M + cidx[rd * KMAXW + r]) * C + c4);
-                f32x4 o;
-                o.x = div_scalar(v.x, sqrtC, inv_sqrtC, recip); o.y = div_scalar(v.y, sqrtC, inv_sqrtC, recip);
-                o.z = div_scalar(v.z, sqrtC, inv_sqrtC, recip); o.w = div_scalar(v.w, sqrtC, inv_sqrtC, recip);
-                *reinterpret_cast<f32x4*>(rows + r * CP + c4) = o;
-            }
-        }
-        __syncthreads();
-        if ((shared_rows || wave == rd) && n < N) {
-            const float* qp = fq + ((size_t)b * N + n) * C;  // wave-uniform -> scalar loads
-            float qn[C];
+        for (int i = 0; i < 32; ++i) qn[i] = div_scalar(qp[ch * 32 + i], sqrtC, inv_sqrtC, recip);
 #pragma unroll
-            for (int c = 0; c < C; ++c) qn[c] = div_scalar(qp[c], sqrtC, inv_sqrtC, recip);
-            const int mqv = mq ? mq[(size_t)b * N + n] : 1;
-            float x[2];
-            unsigned key[2];
+        for (int p = 0; p < 2; ++p) {
+            if (p * 64 < K) {  // wave-uniform
+                f32x4 kr[8];
+                wave_rows32_to_lanes(slab, lane, [&](int r) { return kb + (size_t)cand[min(p * 64 + r, K - 1)] * C + ch * 32; }, kr);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int k = p * 64 + lane;
-                x[p] = 0.f; key[p] = 0u;
-                if (k < K) {
-                    const f32x4* rp = reinterpret_cast<const f32x4*>(rows + k * CP);
-                    float acc = 0.f;
-#pragma unroll
-                    for (int i = 0; i < C / 4; ++i) {
-                        const f32x4 kv = rp[i];
-                        acc = __builtin_fmaf(qn[4 * i + 0], kv.x, acc);
-                        acc = __builtin_fmaf(qn[4 * i + 1], kv.y, acc);
-                        acc = __builtin_fmaf(qn[4 * i + 2], kv.z, acc);
-                        acc = __builtin_fmaf(qn[4 * i + 3], kv.w, acc);
-                    }
-                    float v = div_scalar(acc, T, invT, recip);
-                    if (mq && !(mqv && mk[(size_t)b * M + cidx[wave * KMAXW + k]])) v = NEG_FILL;
-                    x[p] = v; key[p] = f2ord(v);
+                for (int i = 0; i < 8; ++i) {
+                    acc[p] = __builtin_fmaf(qn[4 * i + 0], div_scalar(kr[i].x, sqrtC, inv_sqrtC, recip), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 1], div_scalar(kr[i].y, sqrtC, inv_sqrtC, recip), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 2], div_scalar(kr[i].z, sqrtC, inv_sqrtC, recip), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 3], div_scalar(kr[i].w, sqrtC, inv_sqrtC, recip), acc[p]);
                 }
             }
-            const unsigned wm = wave_max_u32(max(key[0], key[1]));
-            const float m = ord2f(wm);
-            float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
-            float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
-            const float s = wave_sum_f32(e0 + e1);
-            e0 = e0 / s; e1 = e1 / s;
-            if (conf) {
-                if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
-                if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
-            }
-            const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
-            const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
-            const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
-            if (lane == (am & 63)) {
-                next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
-                next_idx[(size_t)b * N + n] = cidx[wave * KMAXW + am];
-            }
         }
+    }
+    const int mqv = mq ? mq[(size_t)b * N + n] : 1;
+    float x[2];
+    unsigned key[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int k = p * 64 + lane;
+        x[p] = 0.f; key[p] = 0u;
+        if (k < K) {
+            float v = div_scalar(acc[p], T, invT, recip);
+            if (mq && !(mqv && mk[(size_t)b * M + (p ? c1 : c0)])) v = NEG_FILL;
+            x[p] = v; key[p] = f2ord(v);
+        }
+    }
+    const unsigned wm = wave_max_u32(max(key[0], key[1]));
+    const float m = ord2f(wm);
+    float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
+    float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
+    const float s = wave_sum_f32(e0 + e1);
+    e0 = e0 / s; e1 = e1 / s;
+    if (conf) {
+        if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
+        if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
+    }
+    const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
+    const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
+    const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+    if (lane == (am & 63)) {
+        next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
+        next_idx[(size_t)b * N + n] = am < 64 ? c0 : c1;
     }
 }
 
 template <int C>
 static int launch_window_match(const float* fq, const float* fk, const int64_t* idx, const uint8_t* mq, const uint8_t* mk,
                                float T, int recip, float* conf, float* next_conf, int64_t* next_idx, int B, int N, int M,
-                               int K, int h, int w, hipStream_t s) {
-    const size_t lds = sizeof(float) * (128 * (C + 4) + 4 * 128 + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_match_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const bool quad = h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N;
+                               int K, hipStream_t s) {
+    const size_t lds = sizeof(float) * 4 * (CASMTR_SLAB_FLOATS + 128);
     const float sqrtC = (float)sqrt((double)C);
-    const dim3 grid(quad ? (h / 2) * (w / 2) : (N + 3) / 4, B);
+    const int nblocks = (N + 3) / 4;
     ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
-    hipLaunchKernelGGL(window_match_kernel<C>, grid, dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC, 1.0f / sqrtC, T,
-                       1.0f / T, recip, conf, next_conf, next_idx, N, M, K, quad ? h : 0, quad ? w : 0);
+    hipLaunchKernelGGL(window_match_kernel<C>, dim3(nblocks, B), dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC, 1.0f / sqrtC,
+                       T, 1.0f / T, recip, conf, next_conf, next_idx, N, M, K, nblocks);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -522,9 +536,11 @@ extern "C" int casmtr_window_match_fwd(const float* feat_q, const float* feat_k,
     if (K > 128 || K <= 0 || (mask_q == nullptr) != (mask_k == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (C == 128) return launch_window_match<128>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
-    if (C == 64) return launch_window_match<64>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
-    if (C == 32) return launch_window_match<32>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    (void)h; (void)w;  // kept in the ABI for callers that know the grid; the kernel no longer needs the hint
+    if (C == 256) return launch_window_match<256>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
+    if (C == 128) return launch_window_match<128>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
+    if (C == 64) return launch_window_match<64>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
+    if (C == 32) return launch_window_match<32>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
     return CASMTR_ERR_UNSUPPORTED;
 }
 

@@ -70,12 +70,14 @@ __global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
     int* cand = reinterpret_cast<int*>(smem);          // [H][KMAX] (MODE 0) or [KMAX]
     float* Sld = smem + CANDN;                         // [4][H][KMAX] logits
     float* Ald = Sld + 4 * H * KMAX;                   // [H][KMAX][4] probabilities
-    float* red = Ald + 4 * H * KMAX;                   // [NSL][4][H*8] float4 partial sums (= 4096 floats)
+    float* red = Sld;                                  // [NSL][4][H*8] float4 partial sums (4096 floats): reuses Sld/Ald
+                                                       // after a barrier (both are dead once the A.V loop has finished)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, n = blockIdx.x;
     const int wq = a.w0 >> 1, Lq = (a.h0 >> 1) * wq, L = a.h0 * a.w0, S = a.h1 * a.w1;
+    const int qidx = xcd_chunk_remap(blockIdx.x, gridDim.x);  // each XCD walks one contiguous range of quads (L2 locality)
+    const int b = qidx / Lq, n = qidx % Lq;
     const int K = 4 * a.Kp;
     const int qy = n / wq, qx = n % wq;
     const int l00 = (2 * qy) * a.w0 + 2 * qx;  // child f -> l00 + (f>>1)*w0 + (f&1)
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
-            const float* qp = a.q + ((size_t)b * L + lf) * HD + h * 32;  // wave-uniform -> s_load
+            const cfloat_p qp = as_const(a.q + ((size_t)b * L + lf) * HD + h * 32);  // wave-uniform -> s_load
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
         for (int f = 0; f < 4; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int* cp = cand + (MODE == 0 ? h * KMAX : 0);
         const float* vb = a.value + (size_t)b * S * HD + h * 32 + dq * 4;
-#pragma unroll 4
+#pragma unroll 8
         for (int k = s; k < K; k += NSL) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(vb + (size_t)cp[k] * HD);
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ald + (h * KMAX + k) * 4);
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
             }
         }
         f32x4* r4 = reinterpret_cast<f32x4*>(red);
+        __syncthreads();  // every thread is done reading Ald before `red` overwrites it
 #pragma unroll
         for (int f = 0; f < 4; ++f) r4[(s * 4 + f) * (H * 8) + item] = acc[f];
         __syncthreads();
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
 template <int H, int KMAX, int MODE>
 static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
     constexpr int CANDN = MODE == 0 ? H * KMAX : KMAX;
-    const size_t lds = sizeof(float) * (CANDN + 8 * H * KMAX + 4096);
+    const size_t lds = sizeof(float) * (CANDN + (8 * H * KMAX > 4096 ? 8 * H * KMAX : 4096));
     const int Lq = (a.h0 / 2) * (a.w0 / 2);
     static bool attr_set = false;  // one process per GPU: no cross-device state to worry about
     if (!attr_set) {
@@ -267,7 +270,7 @@ static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
         attr_set = true;
     }
     ProfScope ps(MODE == 0 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_CASCADE_ATTN, s);
-    hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq, B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq * B), dim3(256), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
