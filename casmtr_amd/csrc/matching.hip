@@ -7,6 +7,7 @@
 // Arithmetic for everything that feeds an index is the oracle's: operands pre-scaled by 1/sqrt(C) (division or
 // reciprocal multiply, `recip`), fp32 fmaf chain over c ascending (v_mfma_f32_32x32x2_f32 is exactly that chain),
 // result scaled by 1/T, masked entries = -1e9, argmax = first maximum of the LOGITS.
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/casmtr_hip.h"
 
@@ -55,15 +56,14 @@ static size_t ds_carve(DsWs* w, char* base, int B, int L, int S) {
 
 extern "C" size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S) { return ds_carve(nullptr, nullptr, B, L, S); }
 
-__global__ __launch_bounds__(256, 2) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+__global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                          const uint8_t* __restrict__ mask0,
                                                          const uint8_t* __restrict__ mask1, float* __restrict__ sim,
                                                          DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
                                                          float T, float invT, int recip) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33]  then  tile[128][129]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33], then epilogue scratch
     float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
     float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
-    float (*tile)[129] = reinterpret_cast<float (*)[129]>(smem);
     const int b = blockIdx.z, i0 = blockIdx.y * DS_BM, j0 = blockIdx.x * DS_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     f32x16 acc[2][2];
@@ -111,57 +111,119 @@ __global__ __launch_bounds__(256, 2) void ds_gemm_kernel(const float* __restrict
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
-    __syncthreads();
-    // epilogue: scale, mask, park in LDS
+    // ------------------------------------------------------------------------------------------------ epilogue
+    // Works from the accumulator registers (a version that parked the tile in LDS and looped over it cost as much as
+    // the whole MFMA loop at one workgroup per CU):
+    //   1. scale by 1/T, apply the padding mask, store the tile straight from registers (128-B coalesced half-waves);
+    //   2. column (max, first argmax, sum exp) over the wave's 64 rows: in-lane scan + one xor-32 exchange;
+    //   3. row statistics over the wave's 64 columns: 32-row slabs through a wave-private LDS region, lane <-> row;
+    //   4. the two waves sharing rows / columns combine through a small LDS exchange -> one partial per 128-wide block.
+    __syncthreads();  // every wave is done reading As/Bs: the region becomes scratch
+    float* wl = smem + wave * (32 * 65);            // wave-private [32][65]
+    float* rowx = smem + 4 * 32 * 65;               // [2 wc][128 rows][3]
+    float* colx = rowx + 2 * 128 * 3;               // [2 wr][128 cols][3]
+    const int hi = lane >> 5, ln = lane & 31;
+    const int NJB = gridDim.x, NIB = gridDim.y;
+    bool colok[2];
+    unsigned char m1v[2] = {1, 1};
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int gj = j0 + wc * 64 + tj * 32 + ln;
+        colok[tj] = gj < S;
+        if (mask0 && colok[tj]) m1v[tj] = mask1[(size_t)b * S + gj];
+    }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int r = 0; r < 16; ++r) {
+            const int gi = i0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool rowok = gi < L;
+            const bool m0v = (mask0 && rowok) ? mask0[(size_t)b * L + gi] != 0 : true;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = wc * 64 + tj * 32 + (lane & 31);
+            for (int tj = 0; tj < 2; ++tj) {
                 float x = div_scalar(acc[ti][tj][r], T, invT, recip);
-                if (mask0) {
-                    const int gi = i0 + row, gj = j0 + col;
-                    const bool ok = gi < L && gj < S && mask0[(size_t)b * L + gi] && mask1[(size_t)b * S + gj];
-                    x = ok ? x : NEG_FILL;
-                }
-                tile[row][col] = x;
+                if (mask0 && !(m0v && m1v[tj])) x = NEG_FILL;
+                const bool ok = rowok && colok[tj];
+                if (ok) sim[((size_t)b * L + gi) * S + j0 + wc * 64 + tj * 32 + ln] = x;
+                acc[ti][tj][r] = ok ? x : -INFINITY;  // out-of-range entries never win a max and add exp(-inf) = 0
             }
-    __syncthreads();
-    const int nr = min(DS_BM, L - i0), nc = min(DS_BN, S - j0);
-    const int NJB = gridDim.x, NIB = gridDim.y;
-    if (tid < 128) {
-        const int r = tid;
-        if (r < nr) {
-            float m = tile[r][0]; int am = 0;
-            for (int c = 1; c < nc; ++c) { const float x = tile[r][c]; if (x > m) { m = x; am = c; } }
-            float s = 0.f;
-            for (int c = 0; c < nc; ++c) s += expf(tile[r][c] - m);
-            const size_t o = ((size_t)b * NJB + blockIdx.x) * L + i0 + r;
-            w.rp_m[o] = m; w.rp_s[o] = s; w.rp_a[o] = j0 + am;
         }
-    } else {
-        const int c = tid - 128;
-        if (c < nc) {
-            float m = tile[0][c]; int am = 0;
-            for (int r = 1; r < nr; ++r) { const float x = tile[r][c]; if (x > m) { m = x; am = r; } }
-            float s = 0.f;
-            for (int r = 0; r < nr; ++r) s += expf(tile[r][c] - m);
-            const size_t o = ((size_t)b * NIB + blockIdx.y) * S + j0 + c;
-            w.cp_m[o] = m; w.cp_s[o] = s; w.cp_a[o] = i0 + am;
+    // ---- 2. columns
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        float m = -INFINITY; int am = 0;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // (ti, r>>2, r&3) ascending == row ascending for this half-wave
+                const float x = acc[ti][tj][r];
+                if (x > m) { m = x; am = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+            }
+        const float pm = __shfl_xor(m, 32);
+        const int pa = __shfl_xor(am, 32);
+        if (pm > m || (pm == m && pa < am)) { m = pm; am = pa; }
+        float sm = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += __expf(acc[ti][tj][r] - m);
+        sm += __shfl_xor(sm, 32);
+        if (hi == 0) {
+            float* o = colx + (wr * 128 + wc * 64 + tj * 32 + ln) * 3;
+            o[0] = m; o[1] = sm; o[2] = __int_as_float(wr * 64 + am);
         }
     }
-    // stream the tile out (row-major [B,L,S])
-    for (int e = tid; e < DS_BM * (DS_BN / 4); e += 256) {
-        const int r = e / (DS_BN / 4), c = (e % (DS_BN / 4)) * 4;
-        if (r >= nr || c >= nc) continue;
-        float* dst = sim + ((size_t)b * L + i0 + r) * S + j0 + c;
-        if ((S & 3) == 0 && c + 3 < nc) {
-            *reinterpret_cast<f32x4*>(dst) = (f32x4){tile[r][c], tile[r][c + 1], tile[r][c + 2], tile[r][c + 3]};
-        } else {
-            for (int u = 0; u < 4 && c + u < nc; ++u) dst[u] = tile[r][c + u];
+    // ---- 3. rows
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) wl[((r & 3) + 8 * (r >> 2) + 4 * hi) * 65 + tj * 32 + ln] = acc[ti][tj][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float* rp = wl + ln * 65 + hi * 32;   // lane <-> (row ln, column half hi)
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = rp[c];
+        float m = -INFINITY; int am = 0;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (v[c] > m) { m = v[c]; am = hi * 32 + c; }
+        const float pm = __shfl_xor(m, 32);
+        const int pa = __shfl_xor(am, 32);
+        if (pm > m || (pm == m && pa < am)) { m = pm; am = pa; }
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sm += __expf(v[c] - m);
+        sm += __shfl_xor(sm, 32);
+        if (hi == 0) {
+            float* o = rowx + (wc * 128 + wr * 64 + ti * 32 + ln) * 3;
+            o[0] = m; o[1] = sm; o[2] = __int_as_float(wc * 64 + am);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    // ---- 4. combine the two waves that share a row (wc = 0,1) / a column (wr = 0,1); the lower block wins ties
+    {
+        const float* x0 = (tid < 128 ? rowx : colx) + (tid & 127) * 3;
+        const float* x1 = x0 + 128 * 3;
+        const float ma = x0[0], mb = x1[0];
+        const float mm = mb > ma ? mb : ma;
+        const int aa = __float_as_int(mb > ma ? x1[2] : x0[2]);
+        float tot = 0.f;
+        if (ma > -INFINITY) tot += x0[1] * __expf(ma - mm);
+        if (mb > -INFINITY) tot += x1[1] * __expf(mb - mm);
+        if (tid < 128) {
+            if (i0 + tid < L) {
+                const size_t o = ((size_t)b * NJB + blockIdx.x) * L + i0 + tid;
+                w.rp_m[o] = mm; w.rp_s[o] = tot; w.rp_a[o] = j0 + aa;
+            }
+        } else if (j0 + tid - 128 < S) {
+            const size_t o = ((size_t)b * NIB + blockIdx.y) * S + j0 + tid - 128;
+            w.cp_m[o] = mm; w.cp_s[o] = tot; w.cp_a[o] = i0 + aa;
         }
     }
 }
@@ -181,7 +243,7 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
         if (x > m) { m = x; am = pa[base + (size_t)k * N]; }
     }
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += ps[base + (size_t)k * N] * expf(pm[base + (size_t)k * N] - m);
+    for (int k = 0; k < nblk; ++k) s += ps[base + (size_t)k * N] * __expf(pm[base + (size_t)k * N] - m);
     omax[t] = m; osum[t] = s; oidx[t] = am; oconf[t] = 1.0f / s;
 }
 
@@ -234,8 +296,8 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
             float rbest = -1.f; int rj = 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float p01 = expf(x[q][u] - rm) * rinv;
-                const float p10 = expf(x[q][u] - cm[u]) * cinv[u];
+                const float p01 = __expf(x[q][u] - rm) * rinv;
+                const float p10 = __expf(x[q][u] - cm[u]) * cinv[u];
                 cf[u] = (j + u < S) ? p10 * p01 : -1.f;
                 if (cf[u] > best[u]) { best[u] = cf[u]; bi[u] = i0 + r; }
                 if (cf[u] > rbest) { rbest = cf[u]; rj = j + u; }
@@ -392,7 +454,7 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C);
     static bool attr_set = false;
-    const size_t gemm_lds = sizeof(float) * 128 * 129;
+    const size_t gemm_lds = sizeof(float) * (4 * 32 * 65 + 2 * 2 * 128 * 3);  // >= the 2 x [128][33] operand tiles
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
         attr_set = true;
