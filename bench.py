@@ -117,23 +117,38 @@ def main():
     pairs_s = B * world * args.steps / dt
     work = algorithmic_work(cfg)
     kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps} for k, v in prof.items()}
-    dom = max(prof.items(), key=lambda kv: kv[1][0])
-    dname, (dms, dn) = dom
+    # ---- roofline of the dominant kernel (largest share of the step), from the HIP events recorded on the launch stream
+    N0 = cfg.hw8[0] * cfg.hw8[1]
+    fine_bytes = 4 * cfg.coarse_dim * (3 * (N0 + N0 // 4) + N0 + N0 // 4 + N0 // 16)  # q,k,v of both fine levels + acc in/out
+    per_launch = {  # kernel -> (bound, algorithmic work per launch for B pairs, unit, formula)
+        "ds_gemm_kernel": ("mfma", work["coarse_flops"] * B, "flop", "2*L*S*C*B"),
+        "quad_attn_kernel<fine>": ("hbm", fine_bytes * B / 2, "B", "4*C*(3*(N0+N1)+N0+N1+N2)*B / 2 launches (levels 1 and 0 averaged)"),
+        "quad_attn_kernel<cascade>": ("hbm", work["cascade_bytes"] * B, "B", "(4*C*4N + 8*(N/4)*25*2 + 8*N*K)*B"),
+        "window_match_kernel": ("hbm", work["match_bytes"] * B / 2, "B", "(8*N*C + 12*N*K + 12*N)*B per direction"),
+        "ds_conf_kernel": ("hbm", 4.0 * N0 * N0 * B, "B", "4*L*S*B (one read of the similarity matrix)"),
+        "nchw_to_tokens_kernel": ("hbm", None, "B", "8*B*C*HW per tensor"),
+    }
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    cand = {k: v for k, v in prof.items() if k in per_launch and per_launch[k][1]}
+    dname, (dms, dn) = max(cand.items(), key=lambda kv: kv[1][0])
     avg_ms = dms / dn
-    hbm_work = {"quad_attn_kernel<fine>": None, "quad_attn_kernel<cascade>": work["cascade_bytes"],
-                "window_match_kernel": work["match_bytes"] / 2}
-    if dname == "ds_gemm_kernel":
-        flops = work["coarse_flops"] * B
-        ach = flops / (avg_ms * 1e-3) / 1e12
-        roof = {"kernel": dname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                "work_per_launch": f"2*L*S*C*B = {flops:.3e} flop (L=S={cfg.hw8[0] * cfg.hw8[1]}, C={cfg.coarse_dim}, B={B})"}
+    bound, wk, unit, formula = per_launch[dname]
+    if bound == "mfma":
+        ach, peak, u = wk / (avg_ms * 1e-3) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
     else:
-        byts = (hbm_work.get(dname) or work["qta_bytes"]) * B
-        ach = byts / (avg_ms * 1e-3) / 1e9
-        roof = {"kernel": dname, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                "work_per_launch": f"{byts:.3e} compulsory bytes"}
+        ach, peak, u = wk / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
+    roof = {"kernel": dname, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
+            "traffic": pmc.get(dname, {}).get("hbm_bytes_per_launch"), "avg_launch_ms": round(avg_ms, 4),
+            "launches_per_step": dn // args.steps, "share_of_step": round(dms / args.steps / ms_step, 3),
+            "work_per_launch": f"{wk:.4e} {unit} = {formula}"}
+    # every hot kernel against its own roof, for the record
+    roofs = {}
+    for k, (ms, n) in prof.items():
+        if k in per_launch and per_launch[k][1]:
+            bd, wk2, _, _ = per_launch[k]
+            a2 = wk2 / (ms / n * 1e-3) / (1e12 if bd == "mfma" else 1e9)
+            roofs[k] = {"bound": bd, "achieved": round(a2, 1), "frac": round(a2 / (PEAK_FP32_MFMA_TFLOPS if bd == "mfma" else PEAK_HBM_GBPS), 4)}
     # chain-level rates for the record (all kernels, not just the dominant one)
     chain = {"algorithmic_GB_per_pair": round(work["total_bytes"] / 1e9, 4), "algorithmic_GFLOP_per_pair": round(work["total_flops"] / 1e9, 2),
              "chain_GBps_per_gpu": round(work["total_bytes"] * B * args.steps / dt / 1e9, 1),
@@ -146,7 +161,7 @@ def main():
                                f"(BASELINE.json configs[1]); 12 QTAttB + dual-softmax + 4 CascadeQTAttB + cascade matching + NMS per pair",
                    "pairs_per_gpu": B, "conf_matrix_materialized": bool(cfg.materialize_conf),
                    "matches_last_step": int(res["n_total"]) if res is not None else None, "parallelism": f"pairs sharded over {world} GPU(s)"},
-        "roofline": roof, "chain": chain, "kernels": kernels,
+        "roofline": roof, "rooflines_all": roofs, "chain": chain, "kernels": kernels,
     }
     if world == 1 and not args.no_cpu_baseline:
         cb, _ = cpu_baseline(cfg, inp)

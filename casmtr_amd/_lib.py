@@ -25,6 +25,7 @@ SIGNATURES = {
     "casmtr_window_score_fwd": (_I, [_P] * 4 + [_I] * 5 + [_P]),
     "casmtr_window_score_bwd": (_I, [_P] * 6 + [_I] * 5 + [_P]),
     "casmtr_nchw_to_tokens": (_I, [_P, _P, _I, _I, _I, _P]),
+    "casmtr_nchw_to_tokens_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "casmtr_qta_coarse_level_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_qta_coarse_level_ws_floats": (_SZ, [_I] * 4),
     "casmtr_qta_fine_level_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),

@@ -13,32 +13,86 @@
 using namespace casmtr;
 
 // =================================================================================================== layout
-// [B,C,HW] -> [B,HW,C], 32x32 LDS tile, both sides coalesced.
-__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ x, float* __restrict__ out, int C,
-                                                             int HW) {
-    __shared__ float t[32][33];
-    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+// [B,C,HW] -> [B,HW,C] for up to 9 tensors in one launch (a QTAttB call converts 3 pyramids x q,k,v).
+// 64x64 tile through LDS; 16-byte global accesses on both sides (pixels contiguous on the way in, channels on the way out).
+#define CASMTR_MAX_LAYOUT 9
+struct LayoutBatch {
+    const float* src[CASMTR_MAX_LAYOUT];
+    float* dst[CASMTR_MAX_LAYOUT];
+    int C[CASMTR_MAX_LAYOUT], HW[CASMTR_MAX_LAYOUT];
+    int tile_begin[CASMTR_MAX_LAYOUT + 1];   // prefix sum of tiles per tensor (per batch element)
+    int n;
+};
+
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const LayoutBatch lb) {
+    __shared__ float t[64][65];
+    int ti = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, p = p0 + tx;
-        if (c < C && p < HW) t[ty + 8 * i][tx] = x[((size_t)b * C + c) * HW + p];
+    for (int i = 1; i < CASMTR_MAX_LAYOUT; ++i)
+        if (i < lb.n && (int)blockIdx.x >= lb.tile_begin[i]) ti = i;
+    const int C = lb.C[ti], HW = lb.HW[ti];
+    const float* __restrict__ x = lb.src[ti];
+    float* __restrict__ out = lb.dst[ti];
+    const int local = blockIdx.x - lb.tile_begin[ti];
+    const int ptiles = (HW + 63) / 64;
+    const int p0 = (local % ptiles) * 64, c0 = (local / ptiles) * 64;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const bool vin = (HW & 3) == 0, vout = (C & 3) == 0;
+    {   // read: thread -> (channel c = tid/16 + 16*i, 4 pixels)
+        const int p = p0 + (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = (tid >> 4) + 16 * i, c = c0 + cl;
+            if (c >= C) continue;
+            const float* src = x + ((size_t)b * C + c) * HW + p;
+            if (vin && p + 3 < HW) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                t[cl][(tid & 15) * 4 + 0] = v.x; t[cl][(tid & 15) * 4 + 1] = v.y;
+                t[cl][(tid & 15) * 4 + 2] = v.z; t[cl][(tid & 15) * 4 + 3] = v.w;
+            } else {
+                for (int u = 0; u < 4; ++u) if (p + u < HW) t[cl][(tid & 15) * 4 + u] = src[u];
+            }
+        }
     }
     __syncthreads();
+    {   // write: thread -> (pixel p = tid/16 + 16*i, 4 channels)
+        const int cl = (tid & 15) * 4, c = c0 + cl;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = p0 + ty + 8 * i, c = c0 + tx;
-        if (c < C && p < HW) out[((size_t)b * HW + p) * C + c] = t[tx][ty + 8 * i];
+        for (int i = 0; i < 4; ++i) {
+            const int pl = (tid >> 4) + 16 * i, p = p0 + pl;
+            if (p >= HW || c >= C) continue;
+            float* dst = out + ((size_t)b * HW + p) * C + c;
+            if (vout && c + 3 < C) {
+                *reinterpret_cast<f32x4*>(dst) = (f32x4){t[cl][pl], t[cl + 1][pl], t[cl + 2][pl], t[cl + 3][pl]};
+            } else {
+                for (int u = 0; u < 4; ++u) if (c + u < C) dst[u] = t[cl + u][pl];
+            }
+        }
     }
 }
 
-extern "C" int casmtr_nchw_to_tokens(const float* x, float* out, int B, int C, int HW, casmtr_stream_t stream) {
-    if (B <= 0 || C <= 0 || HW <= 0) return 0;
+extern "C" int casmtr_nchw_to_tokens_multi(const float* const* src, float* const* dst, const int* C, const int* HW, int n,
+                                           int B, casmtr_stream_t stream) {
+    if (n <= 0 || B <= 0) return 0;
+    if (n > CASMTR_MAX_LAYOUT) return CASMTR_ERR_UNSUPPORTED;
+    LayoutBatch lb{};
+    lb.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        lb.src[i] = src[i]; lb.dst[i] = dst[i]; lb.C[i] = C[i]; lb.HW[i] = HW[i];
+        lb.tile_begin[i] = tiles;
+        tiles += ((HW[i] + 63) / 64) * ((C[i] + 63) / 64);
+    }
+    lb.tile_begin[n] = tiles;
+    if (tiles == 0) return 0;
     ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream);
-    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
-                       (hipStream_t)stream, x, out, C, HW);
+    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, lb);
     CASMTR_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int casmtr_nchw_to_tokens(const float* x, float* out, int B, int C, int HW, casmtr_stream_t stream) {
+    return casmtr_nchw_to_tokens_multi(&x, &out, &C, &HW, 1, B, stream);
 }
 
 // =================================================================================================== quad kernel

@@ -128,10 +128,13 @@ class QTAttB(nn.Module):
         n = len(queries)
         weight = torch.softmax(self.weight.detach().float(), dim=0).tolist()  # 3 scalars -> kernel arguments
         acc = prev_idx = None
-        for i, (query, key, value) in enumerate(zip(reversed(queries), reversed(keys), reversed(values))):
+        # one launch converts all 3 levels x (q,k,v) to token-major rows
+        flat = [t.contiguous().float() for lvl in zip(reversed(queries), reversed(keys), reversed(values)) for t in lvl]
+        toks = ops.nchw_to_tokens_multi(flat)
+        for i, (query, key) in enumerate(zip(reversed(queries), reversed(keys))):
             B, C, h0, w0 = query.shape
             h1, w1 = key.shape[2:]
-            q, k, v = (ops.nchw_to_tokens(t.contiguous().float()) for t in (query, key, value))
+            q, k, v = toks[3 * i:3 * i + 3]
             if i == 0:
                 out = ops.qta_coarse_level(q, k, v, self.nhead, self.topks[0], w_level=weight[0], want_message=False)
             else:
@@ -221,6 +224,6 @@ class CascadeQTAttB(nn.Module):
             return self._forward_composed(query, key, value, topk_pos, rel_pos)
         h0, w0 = query.shape[2:]
         h1, w1 = key.shape[2:]
-        q, k, v = (ops.nchw_to_tokens(t.contiguous().float()) for t in (query, key, value))
+        q, k, v = ops.nchw_to_tokens_multi([t.contiguous().float() for t in (query, key, value)])
         rp = None if rel_pos is None else rel_pos.contiguous().float()
         return ops.cascade_attn(q, k, v, topk_pos.contiguous(), (h0, w0), (h1, w1), self.nhead, self.dilated, rp)

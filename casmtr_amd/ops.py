@@ -120,6 +120,31 @@ def nchw_to_tokens(x):
     return out
 
 
+def nchw_to_tokens_multi(xs):
+    """list of [B,C_i,h_i,w_i] (same B) -> list of [B,h_i*w_i,C_i], one launch for up to 9 tensors."""
+    import ctypes as C
+    outs = []
+    for i in range(0, len(xs), 9):
+        chunk = xs[i:i + 9]
+        for x in chunk:
+            _chk(x, "x")
+        B = chunk[0].shape[0]
+        if any(x.shape[0] != B for x in chunk):
+            raise RuntimeError("nchw_to_tokens_multi: tensors must share the batch size")
+        res = [torch.empty((B, x.shape[2] * x.shape[3], x.shape[1]), device=x.device, dtype=torch.float32) for x in chunk]
+        n = len(chunk)
+        src = (C.c_void_p * n)(*[x.data_ptr() for x in chunk])
+        dst = (C.c_void_p * n)(*[r.data_ptr() for r in res])
+        cs = (C.c_int * n)(*[x.shape[1] for x in chunk])
+        hws = (C.c_int * n)(*[x.shape[2] * x.shape[3] for x in chunk])
+        with torch.cuda.device(chunk[0].device):
+            _lib.check(_lib.lib().casmtr_nchw_to_tokens_multi(C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p),
+                                                              C.cast(cs, C.c_void_p), C.cast(hws, C.c_void_p), n, B,
+                                                              _stream()), "nchw_to_tokens_multi")
+        outs += res
+    return outs
+
+
 def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
     """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")

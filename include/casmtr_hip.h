@@ -63,6 +63,10 @@ int casmtr_window_score_bwd(const float* grad, const float* q, const float* key,
 /* [B,C,h,w] -> [B,h*w,C]   (the `rearrange(x, "b c h w -> b (h w) c")...contiguous()` at
  * cuda_imp/.../modules/quadtree_attention.py:165-167,185-186,413-414)                                           */
 int casmtr_nchw_to_tokens(const float* x, float* out, int B, int C, int HW, casmtr_stream_t stream);
+/* the same for up to 9 tensors in ONE launch (a QTAttB call converts 3 pyramid levels x q,k,v); src/dst/C/HW are HOST
+ * arrays of length n, every tensor has the same B                                                                */
+int casmtr_nchw_to_tokens_multi(const float* const* src, float* const* dst, const int* C, const int* HW, int n, int B,
+                                casmtr_stream_t stream);
 
 /* QTAttB.process_coarse_level (modules/quadtree_attention.py:161-178): dense QK^T (fp32 MFMA) -> softmax over S
  * -> top-k -> A.V.   q [B,L,H,D], k/v [B,S,H,D].

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes).  HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024 (gfx950: FETCH_SIZE
+reports half of a wide coalesced read; calibrated here on ds_conf_kernel, which reads exactly 4*L*S*B bytes) + WRITE_SIZE[KB] * 1024.
+
+    tools/make_pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv profiles/pmc_traffic.json
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+BENCH_NAME = [("quad_attn_kernel<8, 64, 0>", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 128, 0>", "quad_attn_kernel<fine>"),
+              ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("window_match_kernel", "window_match_kernel"),
+              ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
+              ("nchw_to_tokens_kernel", "nchw_to_tokens_kernel"), ("coarse_row_kernel", "coarse_row_kernel"),
+              ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel")]
+
+
+def per_kernel(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            for pat, name in BENCH_NAME:
+                if pat in row["Kernel_Name"]:
+                    tot[name] += float(row["Counter_Value"])
+                    cnt[name] += 1
+                    break
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    f, nf = fetch.get(k, (0.0, 0))
+    w, nw = write.get(k, (0.0, 0))
+    out[k] = {"hbm_bytes_per_launch": round(2 * f * 1024 + w * 1024), "fetch_KB_raw": round(f, 1), "write_KB_raw": round(w, 1),
+              "launches_sampled": max(nf, nw)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
