@@ -68,9 +68,12 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return ord2f(wave_max_u32(f2ord(v)));
 }
 
-__device__ __forceinline__ float div_scalar(float x, float s, float inv_s, int recip) {
-    // torch CPU: true fp32 division; torch GPU kernels: x * fl32(1/s)  (see oracle/casmtr_oracle.c header)
-    return recip ? __fmul_rn(x, inv_s) : __fdiv_rn(x, s);
+// torch CPU: true fp32 division; torch GPU kernels: x * fl32(1/s)  (see oracle/casmtr_oracle.c header).
+// Compile-time switch: with a runtime flag hipcc emits the ~12-instruction IEEE division sequence at every call site
+// (behind a branch), which blew the matching kernels up to 40-65 KB of code -- more than the instruction cache.
+template <bool RECIP>
+__device__ __forceinline__ float div_scalar(float x, float s, float inv_s) {
+    return RECIP ? __fmul_rn(x, inv_s) : __fdiv_rn(x, s);
 }
 
 // Wave-private transposition through LDS: 64 rows x 32 floats (128 B = one cache line each).  Global side: 8 lanes

@@ -56,15 +56,23 @@ static size_t ds_carve(DsWs* w, char* base, int B, int L, int S) {
 
 extern "C" size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S) { return ds_carve(nullptr, nullptr, B, L, S); }
 
+template <bool RECIP>
 __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                          const uint8_t* __restrict__ mask0,
                                                          const uint8_t* __restrict__ mask1, float* __restrict__ sim,
                                                          DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
-                                                         float T, float invT, int recip) {
+                                                         float T, float invT, int NJB, int NIB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33], then epilogue scratch
     float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
     float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
-    const int b = blockIdx.z, i0 = blockIdx.y * DS_BM, j0 = blockIdx.x * DS_BN;
+    // Tile order: 8x8 super-tiles (8 A panels + 8 B panels = 2.1 MB, L2-resident), one contiguous run of super-tiles per
+    // XCD, so that operand panels are fetched from the fabric once per super-tile instead of once per tile.  Speed only.
+    const int NSJ = (NJB + 7) >> 3;
+    const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
+    const int st = t >> 6, wi = t & 63;
+    const int tI = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
+    if (tI >= NIB || tJ >= NJB) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
+    const int b = blockIdx.y, i0 = tI * DS_BM, j0 = tJ * DS_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     f32x16 acc[2][2];
 #pragma unroll
@@ -89,8 +97,8 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                As[lrow][lc0 + 4 * i + c] = div_scalar(av[i][c], sqrtC, inv_sqrtC, recip);
-                Bs[lrow][lc0 + 4 * i + c] = div_scalar(bv[i][c], sqrtC, inv_sqrtC, recip);
+                As[lrow][lc0 + 4 * i + c] = div_scalar<RECIP>(av[i][c], sqrtC, inv_sqrtC);
+                Bs[lrow][lc0 + 4 * i + c] = div_scalar<RECIP>(bv[i][c], sqrtC, inv_sqrtC);
             }
         if (k0 + DS_BK < C) {  // prefetch the next k-tile into registers; it lands while the MFMAs below run
 #pragma unroll
@@ -123,7 +131,6 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
     float* rowx = smem + 4 * 32 * 65;               // [2 wc][128 rows][3]
     float* colx = rowx + 2 * 128 * 3;               // [2 wr][128 cols][3]
     const int hi = lane >> 5, ln = lane & 31;
-    const int NJB = gridDim.x, NIB = gridDim.y;
     bool colok[2];
     unsigned char m1v[2] = {1, 1};
 #pragma unroll
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
             const bool m0v = (mask0 && rowok) ? mask0[(size_t)b * L + gi] != 0 : true;
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) {
-                float x = div_scalar(acc[ti][tj][r], T, invT, recip);
+                float x = div_scalar<RECIP>(acc[ti][tj][r], T, invT);
                 if (mask0 && !(m0v && m1v[tj])) x = NEG_FILL;
                 const bool ok = rowok && colok[tj];
                 if (ok) sim[((size_t)b * L + gi) * S + j0 + wc * 64 + tj * 32 + ln] = x;
@@ -218,11 +225,11 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
         if (mb > -INFINITY) tot += x1[1] * __expf(mb - mm);
         if (tid < 128) {
             if (i0 + tid < L) {
-                const size_t o = ((size_t)b * NJB + blockIdx.x) * L + i0 + tid;
+                const size_t o = ((size_t)b * NJB + tJ) * L + i0 + tid;
                 w.rp_m[o] = mm; w.rp_s[o] = tot; w.rp_a[o] = j0 + aa;
             }
         } else if (j0 + tid - 128 < S) {
-            const size_t o = ((size_t)b * NIB + blockIdx.y) * S + j0 + tid - 128;
+            const size_t o = ((size_t)b * NIB + tI) * S + j0 + tid - 128;
             w.cp_m[o] = mm; w.cp_s[o] = tot; w.cp_a[o] = i0 + aa;
         }
     }
@@ -456,13 +463,19 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     static bool attr_set = false;
     const size_t gemm_lds = sizeof(float) * (4 * 32 * 65 + 2 * 2 * 128 * 3);  // >= the 2 x [128][33] operand tiles
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
         attr_set = true;
     }
     {
         ProfScope ps(CASMTR_PROF_DS_GEMM, s);
-        hipLaunchKernelGGL(ds_gemm_kernel, dim3(NJB, NIB, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws, w,
-                           L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, recip);
+        const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
+        if (recip)
+            hipLaunchKernelGGL(ds_gemm_kernel<true>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB);
+        else
+            hipLaunchKernelGGL(ds_gemm_kernel<false>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB);
     }
     CASMTR_CHECK_LAUNCH();
     prof_begin(CASMTR_PROF_DS_REDUCE, s);
@@ -496,11 +509,11 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
 // (coalesced loads, wave_rows32_to_lanes), every lane normalises its own row chunk and extends its fmaf chain
 // (c ascending across chunks, so the result is the reference's sequential chain).  The query chunk comes in through
 // wave-uniform scalar loads.  lane <-> candidates k = lane and 64 + lane (K <= 128).
-template <int C>
+template <int C, bool RECIP>
 __global__ __launch_bounds__(256) void window_match_kernel(const float* __restrict__ fq, const float* __restrict__ fk,
                                                            const int64_t* __restrict__ idx,
                                                            const uint8_t* __restrict__ mq, const uint8_t* __restrict__ mk,
-                                                           float sqrtC, float inv_sqrtC, float T, float invT, int recip,
+                                                           float sqrtC, float inv_sqrtC, float T, float invT,
                                                            float* __restrict__ conf, float* __restrict__ next_conf,
                                                            int64_t* __restrict__ next_idx, int N, int M, int K,
                                                            int nblocks) {
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(256) void window_match_kernel(const float* __restri
     for (int ch = 0; ch < C / 32; ++ch) {
         float qn[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) qn[i] = div_scalar(qp[ch * 32 + i], sqrtC, inv_sqrtC, recip);
+        for (int i = 0; i < 32; ++i) qn[i] = div_scalar<RECIP>(qp[ch * 32 + i], sqrtC, inv_sqrtC);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (p * 64 < K) {  // wave-uniform
@@ -537,10 +550,10 @@ __global__ __launch_bounds__(256) void window_match_kernel(const float* __restri
                 wave_rows32_to_lanes(slab, lane, [&](int r) { return kb + (size_t)cand[min(p * 64 + r, K - 1)] * C + ch * 32; }, kr);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    acc[p] = __builtin_fmaf(qn[4 * i + 0], div_scalar(kr[i].x, sqrtC, inv_sqrtC, recip), acc[p]);
-                    acc[p] = __builtin_fmaf(qn[4 * i + 1], div_scalar(kr[i].y, sqrtC, inv_sqrtC, recip), acc[p]);
-                    acc[p] = __builtin_fmaf(qn[4 * i + 2], div_scalar(kr[i].z, sqrtC, inv_sqrtC, recip), acc[p]);
-                    acc[p] = __builtin_fmaf(qn[4 * i + 3], div_scalar(kr[i].w, sqrtC, inv_sqrtC, recip), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 0], div_scalar<RECIP>(kr[i].x, sqrtC, inv_sqrtC), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 1], div_scalar<RECIP>(kr[i].y, sqrtC, inv_sqrtC), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 2], div_scalar<RECIP>(kr[i].z, sqrtC, inv_sqrtC), acc[p]);
+                    acc[p] = __builtin_fmaf(qn[4 * i + 3], div_scalar<RECIP>(kr[i].w, sqrtC, inv_sqrtC), acc[p]);
                 }
             }
         }
@@ -553,7 +566,7 @@ __global__ __launch_bounds__(256) void window_match_kernel(const float* __restri
         const int k = p * 64 + lane;
         x[p] = 0.f; key[p] = 0u;
         if (k < K) {
-            float v = div_scalar(acc[p], T, invT, recip);
+            float v = div_scalar<RECIP>(acc[p], T, invT);
             if (mq && !(mqv && mk[(size_t)b * M + (p ? c1 : c0)])) v = NEG_FILL;
             x[p] = v; key[p] = f2ord(v);
         }
@@ -577,18 +590,172 @@ __global__ __launch_bounds__(256) void window_match_kernel(const float* __restri
     }
 }
 
+// Quad variant: one workgroup per quad of query tokens (the 4 children of a coarse cell).  CascadeQTAttB hands every
+// child the same window list (modules/quadtree_attention.py:450), so the K x C key tile is fetched, normalised and staged
+// in LDS ONCE per quad -- 32 channels at a time, double buffered: the loads of chunk c+1 are in flight while the 4 waves
+// (wave <-> child token, lane <-> candidate) extend their fmaf chains over chunk c.  The kernel verifies that the 4 index
+// rows really are identical; if not it walks the tokens one after the other through the same code (same results).
+template <int C, bool RECIP>
+__global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __restrict__ fq, const float* __restrict__ fk,
+                                                                const int64_t* __restrict__ idx,
+                                                                const uint8_t* __restrict__ mq, const uint8_t* __restrict__ mk,
+                                                                float sqrtC, float inv_sqrtC, float T, float invT,
+                                                                float* __restrict__ conf, float* __restrict__ next_conf,
+                                                                int64_t* __restrict__ next_idx, int N, int M, int K, int h,
+                                                                int w, int nquads) {
+    constexpr int KM = 128, RP = 36, NCH = C / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                                        // [2][KM][RP]
+    int* cidx = reinterpret_cast<int*>(smem + 2 * KM * RP);    // [4][KM]
+    int& differ = cidx[4 * KM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int quad = xcd_chunk_remap(blockIdx.x, nquads);      // neighbouring quads (overlapping windows) share an L2
+    const int wq = w >> 1, qy = quad / wq, qx = quad % wq;
+    int tok[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) tok[f] = (2 * qy + (f >> 1)) * w + 2 * qx + (f & 1);
+    if (tid == 0) differ = 0;
+    for (int e = tid; e < 4 * K; e += 256) {
+        const int f = e / K, k = e % K;
+        cidx[f * KM + k] = (int)idx[((size_t)b * N + tok[f]) * K + k];
+    }
+    __syncthreads();
+    {
+        bool d = false;
+        for (int e = tid; e < 3 * K; e += 256) {
+            const int f = 1 + e / K, k = e % K;
+            if (cidx[f * KM + k] != cidx[k]) d = true;
+        }
+        if (d) differ = 1;
+    }
+    __syncthreads();
+    const bool shared_rows = differ == 0;
+    const int rounds = shared_rows ? 1 : 4;
+    const float* kb = fk + (size_t)b * M * C;
+    // staging map: thread -> (row r0 + 32*i, float4 q4 of the 32-channel chunk)
+    const int q4 = tid & 7, r0 = tid >> 3;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int* cl = cidx + rd * KM;                        // the list being staged (everyone's when shared)
+        const bool mine = shared_rows || wave == rd;           // does this wave score against it?
+        const int n = tok[shared_rows ? wave : rd];
+        const cfloat_p qp = as_const(fq + ((size_t)b * N + n) * C);
+        float acc[2] = {0.f, 0.f};
+        f32x4 pre[4];
+        auto issue = [&](int ch) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + 32 * i;
+                if (r < K) pre[i] = *reinterpret_cast<const f32x4*>(kb + ((unsigned)cl[r] * (unsigned)C + (unsigned)(ch * 32 + q4 * 4)));
+            }
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + 32 * i;
+                if (r < K) {
+                    f32x4 o;
+                    o.x = div_scalar<RECIP>(pre[i].x, sqrtC, inv_sqrtC); o.y = div_scalar<RECIP>(pre[i].y, sqrtC, inv_sqrtC);
+                    o.z = div_scalar<RECIP>(pre[i].z, sqrtC, inv_sqrtC); o.w = div_scalar<RECIP>(pre[i].w, sqrtC, inv_sqrtC);
+                    *reinterpret_cast<f32x4*>(tile + (buf * KM + r) * RP + q4 * 4) = o;
+                }
+            }
+        };
+        __syncthreads();   // previous round's readers are done with both buffers
+        issue(0);
+        commit(0);
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + 1 < NCH) issue(ch + 1);               // in flight underneath the chains below
+            if (mine) {
+                float qn[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) qn[i] = div_scalar<RECIP>(qp[ch * 32 + i], sqrtC, inv_sqrtC);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int k = p * 64 + lane;
+                    if (k < K) {
+                        const f32x4* rp = reinterpret_cast<const f32x4*>(tile + ((ch & 1) * KM + k) * RP);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const f32x4 kv = rp[i];
+                            acc[p] = __builtin_fmaf(qn[4 * i + 0], kv.x, acc[p]);
+                            acc[p] = __builtin_fmaf(qn[4 * i + 1], kv.y, acc[p]);
+                            acc[p] = __builtin_fmaf(qn[4 * i + 2], kv.z, acc[p]);
+                            acc[p] = __builtin_fmaf(qn[4 * i + 3], kv.w, acc[p]);
+                        }
+                    }
+                }
+            }
+            if (ch + 1 < NCH) commit((ch + 1) & 1);         // the other buffer: nobody reads it during this chunk
+            __syncthreads();
+        }
+        if (mine) {
+            const int* myc = cidx + (shared_rows ? 0 : rd) * KM;
+            const int c0 = lane < K ? myc[lane] : 0, c1 = 64 + lane < K ? myc[64 + lane] : 0;
+            const int mqv = mq ? mq[(size_t)b * N + n] : 1;
+            float x[2];
+            unsigned key[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int k = p * 64 + lane;
+                x[p] = 0.f; key[p] = 0u;
+                if (k < K) {
+                    float v = div_scalar<RECIP>(acc[p], T, invT);
+                    if (mq && !(mqv && mk[(size_t)b * M + (p ? c1 : c0)])) v = NEG_FILL;
+                    x[p] = v; key[p] = f2ord(v);
+                }
+            }
+            const unsigned wm = wave_max_u32(max(key[0], key[1]));
+            const float m = ord2f(wm);
+            float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
+            float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
+            const float sm = wave_sum_f32(e0 + e1);
+            e0 = e0 / sm; e1 = e1 / sm;
+            if (conf) {
+                if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
+                if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
+            }
+            const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
+            const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
+            const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+            if (lane == (am & 63)) {
+                next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
+                next_idx[(size_t)b * N + n] = am < 64 ? c0 : c1;
+            }
+        }
+    }
+}
+
+template <int C, bool RECIP>
+static int launch_window_match_r(const float* fq, const float* fk, const int64_t* idx, const uint8_t* mq, const uint8_t* mk,
+                                 float T, float* conf, float* next_conf, int64_t* next_idx, int B, int N, int M, int K, int h,
+                                 int w, hipStream_t s) {
+    const float sqrtC = (float)sqrt((double)C);
+    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
+    if (h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N) {
+        const size_t lds = sizeof(float) * (2 * 128 * 36 + 4 * 128 + 4);
+        const int nquads = (h / 2) * (w / 2);
+        hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3(nquads, B), dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC,
+                           1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, h, w, nquads);
+    } else {
+        const size_t lds = sizeof(float) * 4 * (CASMTR_SLAB_FLOATS + 128);
+        const int nblocks = (N + 3) / 4;
+        hipLaunchKernelGGL((window_match_kernel<C, RECIP>), dim3(nblocks, B), dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC,
+                           1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, nblocks);
+    }
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int C>
 static int launch_window_match(const float* fq, const float* fk, const int64_t* idx, const uint8_t* mq, const uint8_t* mk,
                                float T, int recip, float* conf, float* next_conf, int64_t* next_idx, int B, int N, int M,
-                               int K, hipStream_t s) {
-    const size_t lds = sizeof(float) * 4 * (CASMTR_SLAB_FLOATS + 128);
-    const float sqrtC = (float)sqrt((double)C);
-    const int nblocks = (N + 3) / 4;
-    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
-    hipLaunchKernelGGL(window_match_kernel<C>, dim3(nblocks, B), dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC, 1.0f / sqrtC,
-                       T, 1.0f / T, recip, conf, next_conf, next_idx, N, M, K, nblocks);
-    CASMTR_CHECK_LAUNCH();
-    return 0;
+                               int K, int h, int w, hipStream_t s) {
+    return recip ? launch_window_match_r<C, true>(fq, fk, idx, mq, mk, T, conf, next_conf, next_idx, B, N, M, K, h, w, s)
+                 : launch_window_match_r<C, false>(fq, fk, idx, mq, mk, T, conf, next_conf, next_idx, B, N, M, K, h, w, s);
 }
 
 extern "C" int casmtr_window_match_fwd(const float* feat_q, const float* feat_k, const int64_t* idx, const uint8_t* mask_q,
@@ -598,11 +765,10 @@ extern "C" int casmtr_window_match_fwd(const float* feat_q, const float* feat_k,
     if (K > 128 || K <= 0 || (mask_q == nullptr) != (mask_k == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    (void)h; (void)w;  // kept in the ABI for callers that know the grid; the kernel no longer needs the hint
-    if (C == 256) return launch_window_match<256>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
-    if (C == 128) return launch_window_match<128>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
-    if (C == 64) return launch_window_match<64>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
-    if (C == 32) return launch_window_match<32>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, s);
+    if (C == 256) return launch_window_match<256>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    if (C == 128) return launch_window_match<128>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    if (C == 64) return launch_window_match<64>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    if (C == 32) return launch_window_match<32>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
     return CASMTR_ERR_UNSUPPORTED;
 }
 

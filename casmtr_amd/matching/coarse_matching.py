@@ -16,7 +16,7 @@ INF = 1e9
 
 
 class CoarseMatching(nn.Module):
-    def __init__(self, config, coarse_config=None, materialize_conf=True, div_mode="gpu"):
+    def __init__(self, config, coarse_config=None, materialize_conf=True, div_mode="gpu", defer_sync=False):
         super().__init__()
         self.config = config
         self.thr = config["thr"]
@@ -29,6 +29,9 @@ class CoarseMatching(nn.Module):
         self.materialize_conf = materialize_conf
         assert div_mode in ("gpu", "cpu")
         self.recip = div_mode == "gpu"
+        # defer_sync=True: forward() does not read the match count back (no host sync); the match lists stay
+        # capacity-sized until finalize(data, level) is called.  Nothing on the cascade path needs them earlier.
+        self.defer_sync = defer_sync
 
     def _forward_autograd(self, feat_c0, feat_c1, mask_c0, mask_c1):
         """differentiable formulation for training (torch ops on the GPU), coarse_matching.py:62-71"""
@@ -59,8 +62,6 @@ class CoarseMatching(nn.Module):
             out = ops.dual_softmax(feat_c0.contiguous().float(), feat_c1.contiguous().float(), hw0, hw1, self.temperature,
                                    self.thr, self.border_rm, mask_c0, mask_c1, valid, recip=self.recip,
                                    want_conf=self.materialize_conf)
-        n = int(out["n"].item())  # the reference synchronises here too (torch.where, :126)
-        b_ids, i_ids, j_ids, mconf = (out[k][:n] for k in ("b_ids", "i_ids", "j_ids", "mconf"))
         data[f"stage_{level}"] = {
             "conf_matrix": out["conf_matrix"],
             "next_conf_c01_topk": None, "next_idx_c01_topk": None, "next_conf_c10_topk": None, "next_idx_c10_topk": None,
@@ -68,7 +69,20 @@ class CoarseMatching(nn.Module):
             "next_conf_c01": out["next_conf_c01"], "next_conf_c10": out["next_conf_c10"],
             "next_conf_c01_s": None, "next_idx_c01_s": None,
         }
-        data[f"stage_{level}"].update(**self._match_dict(b_ids, i_ids, j_ids, mconf, data, level))
+        data[f"stage_{level}"]["_pending"] = out
+        if not self.defer_sync:
+            self.finalize(data, level)
+
+    @classmethod
+    def finalize(cls, data, level="8c"):
+        """Read the match count back (one host sync, as torch.where at coarse_matching.py:126) and fill the list keys."""
+        st = data[f"stage_{level}"]
+        out = st.pop("_pending", None)
+        if out is None:
+            return
+        n = int(out["n"].item())
+        b_ids, i_ids, j_ids, mconf = (out[k][:n] for k in ("b_ids", "i_ids", "j_ids", "mconf"))
+        st.update(**cls._match_dict(b_ids, i_ids, j_ids, mconf, data, level))
 
     @staticmethod
     def _match_dict(b_ids, i_ids, j_ids, mconf, data, level):

@@ -100,7 +100,7 @@ class HotPath(torch.nn.Module):
         self.coarse_matching = CoarseMatching(
             {"thr": cfg.coarse_thr, "border_rm": cfg.coarse_border_rm, "train_coarse_percent": 0.3,
              "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.coarse_temperature},
-            materialize_conf=cfg.materialize_conf)
+            materialize_conf=cfg.materialize_conf, defer_sync=True)  # one host sync per step, at the end
         post = {"method": "maxpool_nms", "window_size": cfg.nms_window} if cfg.nms_window else {"method": None}
         self.cascade_matching = CascadeMatching(
             {"thr": 0.2, "test_thr": cfg.cascade_test_thr, "pre_thr": [cfg.cascade_pre_thr],
@@ -140,6 +140,7 @@ class HotPath(torch.nn.Module):
         # 5. cascade matching (+ NMS / selection)
         self.cascade_matching(inp["feat_4c0"], inp["feat_4c1"], idx01, idx10, data, level="4c", pre_level="8c")
         st4 = data["stage_4c"]
+        CoarseMatching.finalize(data, "8c")
         return {"messages": msgs, "data": data, "m_bids": st4["m_bids"], "mkpts0": st4["mkpts0_c"],
                 "mkpts1": st4["mkpts1_c"], "mconf": st4["mconf"], "n_coarse": st8["b_ids"].numel()}
 
