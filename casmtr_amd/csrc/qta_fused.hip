@@ -114,7 +114,7 @@ struct QuadArgs {
 };
 
 template <int H, int KMAX, int MODE>
-__global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
+__global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(const QuadArgs a) {
     constexpr int HD = H * 32;
     constexpr int PPH = KMAX / 64;    // 64-candidate passes per head
     constexpr int E = KMAX / 16;      // elements per lane in the 16-lane-row softmax / top-k
@@ -169,8 +169,68 @@ __global__ __launch_bounds__(256) void quad_attn_kernel(const QuadArgs a) {
         }
     }
 
-    // ---- phase 1: logits.  wave <-> (head, 64-candidate pass); lane <-> candidate; query rows through scalar loads.
-    for (int p = wave; p < H * PPH; p += 4) {
+    // ---- phase 1: logits.  wave <-> (head, 64-candidate pass).
+    // Coalesced key reads without an LDS transpose: the 8 lanes of a group share a 128-byte row (one dwordx4 piece each),
+    // so every load instruction covers 8 whole cache lines (a lane-per-row walk touches 64 lines per instruction and is
+    // bound by the L1/TA rate).  The sequential fmaf chain over d then runs as an 8-lane systolic array: lane p owns
+    // d = 4p..4p+3 of its group's 8 rows; a row's accumulator enters at lane 0 and is handed from lane p to lane p+1 with
+    // a DPP row_shr:1, so the arithmetic is exactly the reference's d-ascending chain.  A 3-stage register barrel rotation
+    // (by the lane's piece index) skews the rows so that every lane uses the same register slot in the same step.
+    if (MODE == 0) for (int p = wave; p < H * PPH; p += 4) {
+        const int h = p / PPH;
+        const int kb0 = (p % PPH) * 64;
+        const int g = lane >> 3, pc = lane & 7;
+        const int* cb = cand + (MODE == 0 ? h * KMAX : 0);
+        const float* kbase = a.key + (size_t)b * S * HD + h * 32 + pc * 4;
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(kbase + (size_t)cb[min(kb0 + 8 * g + j, K - 1)] * HD);
+        f32x4 qv[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            qv[f] = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * L + l00 + (f >> 1) * a.w0 + (f & 1)) * HD + h * 32 + pc * 4);
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {   // slot j <- row (j - pc) mod 8
+            f32x4 t8[8];
+            const bool on = (pc & m) != 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 x0 = v[j], x1 = v[(j - m) & 7];
+                t8[j].x = on ? x1.x : x0.x; t8[j].y = on ? x1.y : x0.y; t8[j].z = on ? x1.z : x0.z; t8[j].w = on ? x1.w : x0.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = t8[j];
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 15; ++t) {
+            const f32x4 kv = v[t & 7];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float in = dpp_f32<0x111>(acc[f]);          // row_shr:1 -> the accumulator lane p-1 produced in step t-1
+                in = pc == 0 ? 0.f : in;                     // a chain starts at piece 0
+                in = __builtin_fmaf(qv[f].x, kv.x, in);
+                in = __builtin_fmaf(qv[f].y, kv.y, in);
+                in = __builtin_fmaf(qv[f].z, kv.z, in);
+                in = __builtin_fmaf(qv[f].w, kv.w, in);
+                acc[f] = in;
+            }
+            if (t >= 7 && pc == 7) {                         // row t-7 of the group has seen all 8 pieces
+                const int k = kb0 + 8 * g + (t - 7);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float lg = a.temp * acc[f];
+                    if (MODE == 1 && a.rel_pos && k < K) {
+                        const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
+                        lg = lg + a.rel_pos[(((size_t)b * H + h) * L + lf) * K + k];
+                    }
+                    Sld[(f * H + h) * KMAX + k] = lg;
+                }
+            }
+        }
+    }    // CascadeQTAttB (MODE 1) keeps the lane-per-row walk: with K = 100 the second systolic pass would be half empty and
+    // the extra registers cost it two waves per SIMD (measured 3.5 -> 4.4 ms).
+    if (MODE == 1) for (int p = wave; p < H * PPH; p += 4) {
         const int h = p / PPH;
         const int k = (p % PPH) * 64 + lane;
         const bool valid = k < K;
