@@ -119,11 +119,16 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
     constexpr int PPH = KMAX / 64;    // 64-candidate passes per head
     constexpr int E = KMAX / 16;      // elements per lane in the 16-lane-row softmax / top-k
     constexpr int NSL = 256 / (H * 8);  // candidate slices in the aggregation phase
-    constexpr int CANDN = MODE == 0 ? H * KMAX : KMAX;
+    // LDS strides padded off the 256-byte bank period: the per-head bases of the logits / probabilities / candidate lists
+    // otherwise all fall on the same bank (PMC: bank-conflict cycles 3.7x the useful LDS cycles in the cascade kernel)
+    constexpr int KS = KMAX + 4;          // logits row stride (floats)
+    constexpr int AS = 4 * KMAX + 4;      // probabilities per-head stride (floats)
+    constexpr int CS = KMAX + 1;          // candidate list per-head stride (ints)
+    constexpr int CANDN = (MODE == 0 ? H * CS : CS) + 3 & ~3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* cand = reinterpret_cast<int*>(smem);          // [H][KMAX] (MODE 0) or [KMAX]
-    float* Sld = smem + CANDN;                         // [4][H][KMAX] logits
-    float* Ald = Sld + 4 * H * KMAX;                   // [H][KMAX][4] probabilities
+    float* Sld = smem + CANDN;                         // [4][H][KS] logits
+    float* Ald = Sld + 4 * H * KS;                     // [H][AS] = [H][KMAX][4] probabilities
     float* red = Sld;                                  // [NSL][4][H*8] float4 partial sums (4096 floats): reuses Sld/Ald
                                                        // after a barrier (both are dead once the A.V loop has finished)
 
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
             const int kp = e / H, h = e % H;
             const int64_t p = a.pidx[(((size_t)b * Lq + n) * a.Kp + kp) * H + h];
             const int r = (int)(p / w1p) * 2, c = (int)(p % w1p) * 2;
-            int* cp = cand + h * KMAX + kp * 4;
+            int* cp = cand + h * CS + kp * 4;
             cp[0] = r * a.w1 + c;
             cp[1] = r * a.w1 + c + 1;
             cp[2] = (r + 1) * a.w1 + c;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
         const int h = p / PPH;
         const int kb0 = (p % PPH) * 64;
         const int g = lane >> 3, pc = lane & 7;
-        const int* cb = cand + (MODE == 0 ? h * KMAX : 0);
+        const int* cb = cand + (MODE == 0 ? h * CS : 0);
         const float* kbase = a.key + (size_t)b * S * HD + h * 32 + pc * 4;
         f32x4 v[8];
 #pragma unroll
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
                         const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
                         lg = lg + a.rel_pos[(((size_t)b * H + h) * L + lf) * K + k];
                     }
-                    Sld[(f * H + h) * KMAX + k] = lg;
+                    Sld[(f * H + h) * KS + k] = lg;
                 }
             }
         }
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
         const int h = p / PPH;
         const int k = (p % PPH) * 64 + lane;
         const bool valid = k < K;
-        const int row = cand[(MODE == 0 ? h * KMAX : 0) + (valid ? k : 0)];
+        const int row = cand[(MODE == 0 ? h * CS : 0) + (valid ? k : 0)];
         const f32x4* kp = reinterpret_cast<const f32x4*>(a.key + ((size_t)b * S + row) * HD + h * 32);
         f32x4 kr[8];
 #pragma unroll
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
             }
             float lg = a.temp * acc;
             if (MODE == 1 && a.rel_pos && valid) lg = lg + a.rel_pos[(((size_t)b * H + h) * L + lf) * K + k];
-            Sld[(f * H + h) * KMAX + k] = lg;
+            Sld[(f * H + h) * KS + k] = lg;
         }
     }
     __syncthreads();
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
             const int f = svalid ? sid / H : 0, h = svalid ? sid % H : 0;
             float lv[E];
             unsigned key[E];
-            const f32x4* sp = reinterpret_cast<const f32x4*>(Sld + (f * H + h) * KMAX + j * E);
+            const f32x4* sp = reinterpret_cast<const f32x4*>(Sld + (f * H + h) * KS + j * E);
 #pragma unroll
             for (int e4 = 0; e4 < E / 4; ++e4) {
                 const f32x4 v = sp[e4];
@@ -284,14 +289,14 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                ps[e] = (j * E + e < K) ? expf(lv[e] - m) : 0.f;
+                ps[e] = (j * E + e < K) ? __expf(lv[e] - m) : 0.f;
                 s += ps[e];
             }
-            s = row16_sum_f32(s);
+            s = 1.0f / row16_sum_f32(s);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                ps[e] = ps[e] / s;
-                Ald[(h * KMAX + j * E + e) * 4 + f] = ps[e];
+                ps[e] = ps[e] * s;
+                Ald[h * AS + (j * E + e) * 4 + f] = ps[e];
             }
             if (MODE == 0) {
                 const int lf = l00 + (f >> 1) * a.w0 + (f & 1);
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
                         }
                         if (svalid) {
                             const size_t o = (((size_t)b * L + lf) * a.topk + t) * H + h;
-                            a.topk_idx[o] = cand[h * KMAX + kpos];
+                            a.topk_idx[o] = cand[h * CS + kpos];
                             a.topk_score[o] = sc;
                         }
                     }
@@ -330,12 +335,12 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
         f32x4 acc[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int* cp = cand + (MODE == 0 ? h * KMAX : 0);
+        const int* cp = cand + (MODE == 0 ? h * CS : 0);
         const float* vb = a.value + (size_t)b * S * HD + h * 32 + dq * 4;
 #pragma unroll 8
         for (int k = s; k < K; k += NSL) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(vb + (size_t)cp[k] * HD);
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ald + (h * KMAX + k) * 4);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ald + h * AS + k * 4);
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 acc[f].x = __builtin_fmaf(a4[f], v.x, acc[f].x);
@@ -374,8 +379,9 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
 
 template <int H, int KMAX, int MODE>
 static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
-    constexpr int CANDN = MODE == 0 ? H * KMAX : KMAX;
-    const size_t lds = sizeof(float) * (CANDN + (8 * H * KMAX > 4096 ? 8 * H * KMAX : 4096));
+    constexpr int CANDN = (MODE == 0 ? H * (KMAX + 1) : KMAX + 1) + 3 & ~3;
+    constexpr int BODY = 4 * H * (KMAX + 4) + H * (4 * KMAX + 4);
+    const size_t lds = sizeof(float) * (CANDN + (BODY > 4096 ? BODY : 4096));
     const int Lq = (a.h0 / 2) * (a.w0 / 2);
     static bool attr_set = false;  // one process per GPU: no cross-device state to worry about
     if (!attr_set) {
