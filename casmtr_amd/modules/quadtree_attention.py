@@ -124,9 +124,20 @@ class QTAttB(nn.Module):
         return final.contiguous()
 
     # ---- fused path -------------------------------------------------------------------------------------------
+    def _level_weights(self):
+        """softmax(self.weight) as python floats (they are kernel arguments).  Reading them back is a host sync, so the
+        result is cached until the parameter is modified (tensor version counter / storage change)."""
+        w = self.weight
+        tag = (w._version, w.data_ptr(), str(w.device))
+        cached = getattr(self, "_lw_cache", None)
+        if cached is None or cached[0] != tag:
+            cached = (tag, torch.softmax(w.detach().float(), dim=0).tolist())
+            self._lw_cache = cached
+        return cached[1]
+
     def _forward_fused(self, queries, keys, values):
         n = len(queries)
-        weight = torch.softmax(self.weight.detach().float(), dim=0).tolist()  # 3 scalars -> kernel arguments
+        weight = self._level_weights()
         acc = prev_idx = None
         # one launch converts all 3 levels x (q,k,v) to token-major rows
         flat = [t.contiguous().float() for lvl in zip(reversed(queries), reversed(keys), reversed(values)) for t in lvl]
