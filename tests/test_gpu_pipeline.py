@@ -192,3 +192,83 @@ def test_full_size_chain_vs_oracle(B):
     assert np.array_equal(ni10[b_ids, j_ids], i_ids), "double check"
     assert (nc01[b_ids, i_ids] > cfg.cascade_test_thr).all()
     assert (np.diff(b_ids * 10**6 + i_ids) > 0).all(), "(b,i) ordering"
+
+
+def _rand(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def test_2c_level_shapes_vs_oracle():
+    """BASELINE configs[3] (CasMTR-2c, 1/2-res cascade): H = 2, C = 64, 416x416 query grid, K = 100."""
+    from casmtr_amd import ops
+    hc, wc, H, C = 208, 208, 2, 64
+    h, w = 2 * hc, 2 * wc
+    r = np.random.default_rng(11)
+    coarse_idx = r.integers(0, hc * wc, (1, hc * wc), dtype=np.int64)
+    tp = ops.window_warp_idx(T(coarse_idx), hc, wc, 5)
+    assert np.array_equal(N(tp), oracle.window_warp_idx(coarse_idx, hc, wc, 5))
+    q, k, v = (_rand((1, h * w, C), s) for s in (1, 2, 3))
+    msg, up = ops.cascade_attn(T(q), T(k), T(v), tp, (h, w), (h, w), H)
+    mo, uo = oracle.cascade_attn(q, k, v, N(tp), (h, w), (h, w), H)
+    assert np.array_equal(N(up), uo)
+    assert_close(N(msg), mo, TOL, "2c cascade message (173056 tokens)")
+    f0, f1 = 3.0 * _rand((1, h * w, C), 4), 3.0 * _rand((1, h * w, C), 5)
+    d = ops.window_match(T(f0), T(f1), up, 1.0, recip=True, hw=(h, w))
+    o = oracle.window_match(f0, f1, uo, 1.0, recip=True)
+    assert np.array_equal(N(d["next_idx"]), o["next_idx"]), "2c window argmax (173056 x 100) must be bit-exact"
+    assert_close(N(d["conf_matrix"]), o["conf_matrix"], TOL, "2c conf")
+    # two previous stages (8c and 4c) feed the 2c selection (pre_thr = [[0.2],[0.2,0.2]], NMS on 2c only)
+    pre8, pre4 = r.random((1, 104 * 104), dtype=np.float32), r.random((1, hc * wc), dtype=np.float32)
+    sel = ops.nms_select(d["next_conf"], d["next_idx"], d["next_idx"], (h, w), (h, w), nms_window=5, test_thr=0.05,
+                         pre=[(T(pre8), (104, 104), 0.2), (T(pre4), (hc, wc), 0.2)], border_rm=2, double_check=False)
+    so = oracle.nms_select(N(d["next_conf"]), N(d["next_idx"]), N(d["next_idx"]), (h, w), (h, w), nms_window=5, test_thr=0.05,
+                           pre=[(pre8, (104, 104), 0.2), (pre4, (hc, wc), 0.2)], border_rm=2, double_check=False)
+    n = int(sel["n"].item())
+    assert n == len(so["b_ids"]) and n > 50
+    assert np.array_equal(N(sel["i_ids"][:n]), so["i_ids"]) and np.array_equal(N(sel["j_ids"][:n]), so["j_ids"])
+
+
+def test_indoor_shapes_vs_oracle():
+    """BASELINE configs[4] shapes (ScanNet indoor 640x480): 80x60 coarse grid, topks [32,16,16], rel_pos in the cascade."""
+    from casmtr_amd import ops
+    from casmtr_amd.modules.quadtree_attention import CascadeQTAttB, QTAttB
+    H, D = 8, 32
+    hh, ww = 60, 80
+
+    def pyr(seed):
+        x = _rand((1, H * D, hh, ww), seed)
+        out = [x]
+        for _ in range(2):
+            b, c, a, bb = x.shape
+            x = np.ascontiguousarray(x.reshape(b, c, a // 2, 2, bb // 2, 2).mean(axis=(3, 5), dtype=np.float32))
+            out.append(x)
+        return out
+
+    qs, ks, vs = pyr(21), pyr(22), pyr(23)
+    wt = _rand((3,), 24)
+    m = QTAttB(H, D, scale=3, topks=[32, 16, 16]).to(DEV).eval()
+    with torch.no_grad():
+        m.weight.copy_(T(wt))
+        out = m([T(x) for x in qs], [T(x) for x in ks], [T(x) for x in vs])
+    fo, lv = oracle.qtattb_forward(qs, ks, vs, wt, H, [32, 16, 16])
+    assert_close(N(out), fo, TOL, "indoor QTAttB message (80x60)")
+    # per-level indices through the ops (the module does not expose them)
+    tok = lambda x: np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(1, -1, H * D))
+    c = ops.qta_coarse_level(T(tok(qs[2])), T(tok(ks[2])), T(tok(vs[2])), H, 32)
+    assert np.array_equal(N(c["topk_idx"]), lv[0]["topk_idx"])
+    f1 = ops.qta_fine_level(T(tok(qs[1])), T(tok(ks[1])), T(tok(vs[1])), c["topk_idx"], (30, 40), (30, 40), H, 16)
+    assert np.array_equal(N(f1["topk_idx"]), lv[1]["topk_idx"]), "indoor level-1 top-16 of 128"
+    # cascade with relative position bias: [B, nhead, H0*W0, 4*ww]
+    hc, wc, Hc = 60, 80, 4
+    h, w = 2 * hc, 2 * wc
+    r = np.random.default_rng(31)
+    tp = oracle.window_warp_idx(r.integers(0, hc * wc, (1, hc * wc), dtype=np.int64), hc, wc, 5)
+    q, k, v = (_rand((1, 128, h, w), s) for s in (32, 33, 34))
+    rel = _rand((1, Hc, h * w, 100), 35)
+    cm = CascadeQTAttB(Hc, 32, dilated=1).to(DEV)
+    with torch.no_grad():
+        msg, up = cm(T(q), T(k), T(v), T(tp), T(rel))
+    tk = lambda x: np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(1, h * w, 128))
+    mo, uo = oracle.cascade_attn(tk(q), tk(k), tk(v), tp, (h, w), (h, w), Hc, rel_pos=rel)
+    assert np.array_equal(N(up), uo)
+    assert_close(N(msg), mo, TOL, "indoor cascade message with rel_pos (160x120)")
