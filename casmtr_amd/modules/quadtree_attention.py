@@ -42,6 +42,16 @@ def _raster_order(x, h, w):
     return x.permute(*perm).reshape(B, h * w, *rest)
 
 
+def _unquad_rows(x, H):
+    """einops "b (H W) (t1 t2) ... -> b (H t1 W t2) ..." with an explicit H (W = L/H), exactly as the reference spells its
+    merge step.  Equal to _raster_order when H is the quad-grid height."""
+    B, Lq = x.shape[:2]
+    rest = x.shape[3:]
+    x = x.view(B, H, Lq // H, 2, 2, *rest)
+    perm = (0, 1, 3, 2, 4) + tuple(range(5, 5 + len(rest)))
+    return x.permute(*perm).reshape(B, Lq * 4, *rest)
+
+
 def _children(topk_pos, w1, dilated=1):
     """(row,col) on the coarser grid [2,B,N,K,H] -> child indices on the finer grid [B,N,K,4,H]  (:193-199)"""
     r, c = topk_pos[0] * 2, topk_pos[1] * 2
@@ -185,20 +195,63 @@ class QTAttGuided(QTAttB):
         final = None
         for i, m in enumerate(messages):
             final = m * weight[i] if i == 0 else final.unsqueeze(2) + m * weight[i]
-            hq, wq = queries[-(i + 1)].shape[2:]
-            final = _raster_order(final, hq, wq)
+            # literal reference behaviour (:384): H = queries[-i].shape[2]; for i == 0 that is queries[0], the FINEST
+            # level, so the first message stays in quad-major order -- kept bug-for-bug (no shipped config uses Guided)
+            final = _unquad_rows(final, queries[-i].shape[2])
         return final.contiguous()
 
 
 class QTAttA(nn.Module):
-    """Variant A (modules/quadtree_attention.py:8-140).  No shipped config selects it (`attn_type='B'`, SURVEY.md §8
-    a13 / §8(f)-4); the name exists so that `from ... import QTAttA, QTAttB, CascadeQTAttB, QTAttGuided`
-    (src/model/modules/quadtree_attention.py:6) keeps working.  Constructing it fails loudly instead of silently
-    computing something else."""
+    """Variant A (modules/quadtree_attention.py:8-140): the top-k tokens of a level are masked out of that level's
+    message and re-attended at the next level, where each parent's score is redistributed over its 4 children
+    (softmax over the children, times the parent's score).  No learned level weights.  No shipped config selects it
+    (`attn_type='B'` everywhere); it runs on the composed path: HIP primitives (score / value
+    aggregation, with backward) + torch softmax / top-k on the GPU."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, nhead, dim, topks=[32, 32, 32, 32], scale=None, use_dropout=False, attention_dropout=0.1):
         super().__init__()
-        raise NotImplementedError("QTAttA is not part of the MI355X hot path (no shipped CasMTR config uses attn_type='A')")
+        self.use_dropout = use_dropout
+        self.topks = topks
+        self.nhead = nhead
+        self.dim = dim
+
+    def forward(self, queries, keys, values, q_mask=None, kv_mask=None):
+        nh = self.nhead
+        n_levels = len(queries)
+        topk = self.topks[0]
+        final = topk_score = topk_pos = None
+        for i, (query, key, value) in enumerate(zip(reversed(queries), reversed(keys), reversed(values))):
+            bs, c, h, w = key.shape
+            k_, v_ = _tokens(key, nh), _tokens(value, nh)
+            temp = 1.0 / k_.shape[-1] ** 0.5
+            if i == 0:   # full attention, top-k masked out of the message (:24-44)
+                q_ = _tokens(query, nh)
+                A = torch.softmax(torch.einsum("nlhd,nshd->nlsh", q_, k_) * temp, dim=-2)
+                topk_score, topk_idx = torch.topk(A, dim=-2, k=topk, largest=True)
+                message = torch.einsum("nlsh,nshd->nlhd", A.scatter(-2, topk_idx, 0.0), v_)
+            else:        # (:46-97)
+                topk_prev, topk = topk, self.topks[i]
+                last = i == n_levels - 1
+                h0, w0 = query.shape[2:]
+                q_ = _quad_order(_tokens(query, nh), h0, w0).contiguous()
+                idx = _children(topk_pos, w).reshape(bs, -1, topk_prev * 4, nh).contiguous()
+                QK = score_computation_op(q_, k_.contiguous(), idx).view(bs, -1, 4, topk_prev, 4, nh) * temp
+                A = torch.softmax(QK, dim=-2) * topk_score.unsqueeze(-2).unsqueeze(2)   # score redistribution
+                A = A.reshape(bs, -1, 4, topk_prev * 4, nh)
+                idx5 = idx.unsqueeze(2).expand(-1, -1, 4, -1, -1).contiguous()
+                topk_score, topk_i = torch.topk(A, dim=-2, k=topk, largest=True)
+                Am = A if last else A.scatter(-2, topk_i, 0.0)
+                message = value_aggregation_op(Am.contiguous(), v_.contiguous(), idx5)
+                if not last:
+                    topk_idx = _raster_order(torch.gather(idx5, index=topk_i, dim=-2), h0, w0)
+                    topk_score = _raster_order(topk_score, h0, w0)
+            if i == 0:
+                final = message
+            else:
+                final = _raster_order(final.unsqueeze(2) + message, *query.shape[2:])
+            if i < n_levels - 1:
+                topk_pos = torch.stack([torch.div(topk_idx, w, rounding_mode="trunc"), topk_idx % w])
+        return final
 
 
 class CascadeQTAttB(nn.Module):

@@ -198,6 +198,22 @@ def gen_qtattb():
         save("qtattb_" + name, **out)
 
 
+def gen_qtatt_variants():
+    for name, cfg in CASES["qtatt_variants"].items():
+        inp = make_inputs("qtatt_variants", name)
+        qs, ks, vs = ([T(x) for x in inp[n]] for n in ("queries", "keys", "values"))
+        H, D = cfg["nhead"], cfg["D"]
+        with torch.no_grad():
+            if cfg["kind"] == "A":
+                m = qta.QTAttA(H, D, topks=cfg["topks"])
+                final = m(qs, ks, vs)
+            else:
+                m = qta.QTAttGuided(H, D, scale=len(cfg["topks"]), topks=cfg["topks"])
+                m.weight.copy_(T(inp["weight"]))
+                final = m(qs, ks, vs, topk_pos=T(inp["topk_pos"]))
+        save("qtatt_variants_" + name, checksum=checksum(inp), final=final)
+
+
 def window_offsets(ws):
     w, _ = get_propagations({"propagation": "window", "window_size": ws})
     return w
@@ -286,6 +302,6 @@ def gen_cascade_matching():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "qtattb", "cascade_attn", "coarse_matching", "cascade_matching"]
+    which = sys.argv[1:] or ["ops", "qtattb", "qtatt_variants", "cascade_attn", "coarse_matching", "cascade_matching"]
     for w in which:
         globals()["gen_" + w]()

@@ -18,6 +18,11 @@ CASES = {
         "g40x32": dict(seed=23, B=1, hw=(40, 32), nhead=8, D=32, topks=[32, 16, 8]),
         "g40x32_indoor": dict(seed=24, B=1, hw=(40, 32), nhead=8, D=32, topks=[32, 16, 16]),
     },
+    # a13: variants no shipped config selects (QTAttA; QTAttGuided starts from externally supplied positions)
+    "qtatt_variants": {
+        "a_g16x16": dict(seed=61, B=1, hw=(16, 16), nhead=8, D=32, topks=[8, 4, 2], kind="A"),
+        "guided_g16x16": dict(seed=62, B=1, hw=(16, 16), nhead=4, D=32, topks=[4, 4], kind="Guided"),
+    },
     "cascade_attn": {
         "c16_f32": dict(seed=31, B=2, coarse_hw=(16, 16), nhead=4, D=32, ws=5),
         "c12x20_relpos": dict(seed=32, B=1, coarse_hw=(12, 20), nhead=4, D=32, ws=5, rel_pos=True),
@@ -96,6 +101,17 @@ def make_inputs(group, name):
         k = _pyramid(_randn(r, B, C, hk, wk))
         v = _pyramid(_randn(r, B, C, hk, wk))
         return dict(queries=q, keys=k, values=v, weight=_randn(r, 3))
+    if group == "qtatt_variants":
+        B, (h, w), H, D = cfg["B"], cfg["hw"], cfg["nhead"], cfg["D"]
+        C, n = H * D, len(cfg["topks"])
+        q, k, v = (_pyramid(_randn(r, B, C, h, w), n) for _ in range(3))
+        out = dict(queries=q, keys=k, values=v, weight=_randn(r, n))
+        if cfg["kind"] == "Guided":   # (row, col) on the half-resolution grid of the coarsest level
+            hc, wc = h >> (n - 1), w >> (n - 1)
+            pos = np.stack([r.integers(0, hc // 2, (B, (hc // 2) * (wc // 2), cfg["topks"][0], H)),
+                            r.integers(0, wc // 2, (B, (hc // 2) * (wc // 2), cfg["topks"][0], H))]).astype(np.int64)
+            out["topk_pos"] = pos
+        return out
     if group == "cascade_attn":
         B, (hc, wc), H, D = cfg["B"], cfg["coarse_hw"], cfg["nhead"], cfg["D"]
         C, h, w = H * D, hc * 2, wc * 2

@@ -95,8 +95,7 @@ def test_drop_in_names():
     assert any(k.startswith("get_vs.0.") for k in ml.state_dict())
     assert list(CascadeQTAttB(4, 32, dilated=None).state_dict()) == [] and CascadeQTAttB(4, 32, None).dilated == 1
     assert list(QTAttGuided(8, 32, 3, topks=[16, 8, 8]).state_dict()) == ["weight"]
-    with pytest.raises(NotImplementedError):
-        QTAttA(8, 32)
+    assert list(QTAttA(8, 32, topks=[8, 4, 2]).state_dict()) == []   # variant A has no parameters (:8-22)
     with pytest.raises(NotImplementedError):
         PostProcess({"method": "sift"})
     assert PostProcess({"method": "maxpool_nms", "window_size": 5}).nms_window == 5

@@ -272,3 +272,22 @@ def test_indoor_shapes_vs_oracle():
     mo, uo = oracle.cascade_attn(tk(q), tk(k), tk(v), tp, (h, w), (h, w), Hc, rel_pos=rel)
     assert np.array_equal(N(up), uo)
     assert_close(N(msg), mo, TOL, "indoor cascade message with rel_pos (160x120)")
+
+
+@pytest.mark.parametrize("name", list(CASES["qtatt_variants"]))
+def test_qtatt_variants_vs_reference(name):
+    """QTAttA and QTAttGuided (no shipped config selects them) against the reference python."""
+    from casmtr_amd.modules.quadtree_attention import QTAttA, QTAttGuided
+    inp = make_inputs("qtatt_variants", name)
+    cfg = CASES["qtatt_variants"][name]
+    g = load_golden("qtatt_variants", name)
+    qs, ks, vs = ([T(x) for x in inp[n]] for n in ("queries", "keys", "values"))
+    with torch.no_grad():
+        if cfg["kind"] == "A":
+            out = QTAttA(cfg["nhead"], cfg["D"], topks=cfg["topks"]).to(DEV)(qs, ks, vs)
+        else:
+            m = QTAttGuided(cfg["nhead"], cfg["D"], scale=len(cfg["topks"]), topks=cfg["topks"]).to(DEV)
+            m.weight.copy_(T(inp["weight"]))
+            out = m(qs, ks, vs, topk_pos=T(inp["topk_pos"]))
+    assert out.shape == g["final"].shape
+    assert_close(N(out), g["final"], TOL, f"{cfg['kind']} final message vs reference python")
