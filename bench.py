@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--materialize-conf", action="store_true", help="also write the [B,L,S] conf_matrix (drop-in default)")
+    ap.add_argument("--channels-last", action="store_true",
+                    help="q/k/v pyramids arrive channels_last in memory (zero-copy token view); NOT the headline configuration")
     args = ap.parse_args()
 
     rank, world, local = cdist.init_from_env()
@@ -86,7 +88,7 @@ def main():
     cfg = HotPathConfig(materialize_conf=args.materialize_conf)
     B = args.batch
     model = HotPath(cfg).to(device)
-    inp = make_synthetic_inputs(cfg, B, device, seed=1234 + rank)
+    inp = make_synthetic_inputs(cfg, B, device, seed=1234 + rank, channels_last=args.channels_last)
     with torch.no_grad():
         model.qta.weight.copy_(inp["weight"])
     cdist.broadcast_parameters(model)          # RCCL broadcast of the (tiny) parameter buffer from rank 0
@@ -160,6 +162,7 @@ def main():
         "config": {"workload": f"{cfg.name}, random-init, batch of {B} synthetic 832x832 pairs per GPU "
                                f"(BASELINE.json configs[1]); 12 QTAttB + dual-softmax + 4 CascadeQTAttB + cascade matching + NMS per pair",
                    "pairs_per_gpu": B, "conf_matrix_materialized": bool(cfg.materialize_conf),
+                   "qkv_memory_format": "channels_last" if args.channels_last else "contiguous (NCHW)",
                    "matches_last_step": int(res["n_total"]) if res is not None else None, "parallelism": f"pairs sharded over {world} GPU(s)"},
         "roofline": roof, "rooflines_all": roofs, "chain": chain, "kernels": kernels,
     }

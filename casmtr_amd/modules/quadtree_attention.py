@@ -150,7 +150,7 @@ class QTAttB(nn.Module):
         weight = self._level_weights()
         acc = prev_idx = None
         # one launch converts all 3 levels x (q,k,v) to token-major rows
-        flat = [t.contiguous().float() for lvl in zip(reversed(queries), reversed(keys), reversed(values)) for t in lvl]
+        flat = [t.float() for lvl in zip(reversed(queries), reversed(keys), reversed(values)) for t in lvl]
         toks = ops.nchw_to_tokens_multi(flat)
         for i, (query, key) in enumerate(zip(reversed(queries), reversed(keys))):
             B, C, h0, w0 = query.shape
@@ -288,6 +288,6 @@ class CascadeQTAttB(nn.Module):
             return self._forward_composed(query, key, value, topk_pos, rel_pos)
         h0, w0 = query.shape[2:]
         h1, w1 = key.shape[2:]
-        q, k, v = ops.nchw_to_tokens_multi([t.contiguous().float() for t in (query, key, value)])
+        q, k, v = ops.nchw_to_tokens_multi([t.float() for t in (query, key, value)])
         rp = None if rel_pos is None else rel_pos.contiguous().float()
         return ops.cascade_attn(q, k, v, topk_pos.contiguous(), (h0, w0), (h1, w1), self.nhead, self.dilated, rp)

@@ -120,12 +120,26 @@ def nchw_to_tokens(x):
     return out
 
 
+def _is_channels_last(x):
+    B, C, h, w = x.shape
+    return x.dtype == torch.float32 and x.stride() == (h * w * C, 1, w * C, C)
+
+
 def nchw_to_tokens_multi(xs):
-    """list of [B,C_i,h_i,w_i] (same B) -> list of [B,h_i*w_i,C_i], one launch for up to 9 tensors."""
+    """list of [B,C_i,h_i,w_i] (same B) -> list of [B,h_i*w_i,C_i], one launch for up to 9 tensors.
+    Tensors that already are channels_last in memory (what MIOpen convolutions prefer) are token-major as they stand: they
+    are returned as zero-copy views and skip the kernel."""
     import ctypes as C
-    outs = []
-    for i in range(0, len(xs), 9):
-        chunk = xs[i:i + 9]
+    outs = [None] * len(xs)
+    todo = []
+    for i, x in enumerate(xs):
+        if x.dim() == 4 and x.is_cuda and _is_channels_last(x):
+            outs[i] = x.permute(0, 2, 3, 1).reshape(x.shape[0], x.shape[2] * x.shape[3], x.shape[1])
+        else:
+            todo.append(i)
+    for j in range(0, len(todo), 9):
+        ids = todo[j:j + 9]
+        chunk = [xs[i] if xs[i].is_contiguous() else xs[i].contiguous() for i in ids]
         for x in chunk:
             _chk(x, "x")
         B = chunk[0].shape[0]
@@ -141,7 +155,8 @@ def nchw_to_tokens_multi(xs):
             _lib.check(_lib.lib().casmtr_nchw_to_tokens_multi(C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p),
                                                               C.cast(cs, C.c_void_p), C.cast(hws, C.c_void_p), n, B,
                                                               _stream()), "nchw_to_tokens_multi")
-        outs += res
+        for i, r in zip(ids, res):
+            outs[i] = r
     return outs
 
 

@@ -72,7 +72,7 @@ def _warp_tokens(f0, hw, shift, noise, gen):
     return f1.contiguous()
 
 
-def make_synthetic_inputs(cfg: HotPathConfig, B: int, device, seed: int = 0) -> Dict[str, object]:
+def make_synthetic_inputs(cfg: HotPathConfig, B: int, device, seed: int = 0, channels_last: bool = False) -> Dict[str, object]:
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     h8, w8 = cfg.hw8
@@ -83,6 +83,10 @@ def make_synthetic_inputs(cfg: HotPathConfig, B: int, device, seed: int = 0) -> 
         for n in "qkv":
             inp[f"c{n}{im}"] = _pyramid(rn(B, cfg.coarse_dim, h8, w8))       # QuadtreeAttention.forward :78-89
             inp[f"f{n}{im}"] = rn(B, cfg.cascade_dim, h4, w4)                 # CascadeQuadtreeAttention.forward
+    if channels_last:   # same [B,C,H,W] tensors, NHWC in memory (the layout MIOpen convolutions produce when asked to)
+        for key in list(inp):
+            v = inp[key]
+            inp[key] = [t.contiguous(memory_format=torch.channels_last) for t in v] if isinstance(v, list) else v.contiguous(memory_format=torch.channels_last)
     inp["weight"] = rn(3)
     inp["feat_8c0"] = rn(B, h8 * w8, cfg.coarse_dim)
     inp["feat_8c1"] = _warp_tokens(inp["feat_8c0"], (h8, w8), (3, 5), 0.35, g)

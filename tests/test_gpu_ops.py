@@ -84,6 +84,14 @@ def test_nchw_to_tokens(ops):
     assert np.array_equal(N(out), x.transpose(0, 2, 3, 1).reshape(2, 9 * 13, 70))
 
 
+def test_channels_last_is_zero_copy(ops):
+    x = torch.randn(2, 64, 6, 10, device=DEV)
+    xl = x.contiguous(memory_format=torch.channels_last)
+    a, b = ops.nchw_to_tokens_multi([x, xl])
+    assert torch.equal(a, b) and b.data_ptr() == xl.data_ptr() and a.data_ptr() != x.data_ptr()
+    assert b.is_contiguous() and b.shape == (2, 60, 64)
+
+
 def _tok(x):
     B, C, h, w = x.shape
     return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(B, h * w, C))
