@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   kernels      : per-kernel ms/step breakdown (same events)
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -30,6 +31,9 @@ from casmtr_amd import _lib, dist as cdist  # noqa: E402
 from casmtr_amd.pipeline import HotPath, HotPathConfig, algorithmic_work, make_synthetic_inputs  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# kernels with an algorithmic-work formula (candidates for the dominant-kernel roofline)
+ROOFLINE_KERNELS = ("ds_gemm_kernel", "quad_attn_kernel<fine>", "quad_attn_kernel<cascade>", "window_match_kernel",
+                    "ds_conf_kernel", "linear_nt_kernel")
 PEAK_HBM_GBPS = 8000.0          # same guide, HBM3E peak (6.3 TB/s achievable)
 
 
@@ -76,6 +80,9 @@ def main():
     ap.add_argument("--materialize-conf", action="store_true", help="also write the [B,L,S] conf_matrix (drop-in default)")
     ap.add_argument("--channels-last", action="store_true",
                     help="q/k/v pyramids arrive channels_last in memory (zero-copy token view); NOT the headline configuration")
+    ap.add_argument("--with-callers", action="store_true",
+                    help="SURVEY.md section 8 f.1 workload: enter through QuadtreeAttention / CascadeQuadtreeAttention on [B,N,C] "
+                         "tokens (q/k/v + output projections and the pyramid inside the step); NOT the headline configuration")
     args = ap.parse_args()
 
     rank, world, local = cdist.init_from_env()
@@ -85,7 +92,7 @@ def main():
     torch.cuda.set_device(device)
     _lib.lib()  # fail loudly here if the HIP library is missing
 
-    cfg = HotPathConfig(materialize_conf=args.materialize_conf)
+    cfg = HotPathConfig(materialize_conf=args.materialize_conf, callers=args.with_callers)
     B = args.batch
     model = HotPath(cfg).to(device)
     inp = make_synthetic_inputs(cfg, B, device, seed=1234 + rank, channels_last=args.channels_last)
@@ -97,11 +104,32 @@ def main():
         out = model(inp)
         return cdist.gather_matches(out, pairs_per_rank=B)  # counts all-gather + gather of [M,5] / [M] to rank 0
 
-    for _ in range(args.warmup):
+    # Warm-up.  Its last (up to) two steps run with every kernel timed by HIP events: that survey names the dominant kernel
+    # and fills the per-kernel table.  In the timed region only the dominant kernel keeps its two event records per launch
+    # (each record serialises ~3 us on the stream; timing all ~75 launches/step costs ~2 % of the step).
+    n_survey = min(2, args.warmup)
+    for _ in range(args.warmup - n_survey):
         step()
+    survey = {}
+    if n_survey:
+        torch.cuda.synchronize()
+        _lib.prof_enable(True)
+        for _ in range(n_survey):
+            step()
+        torch.cuda.synchronize()
+        survey = _lib.prof_read()
+        _lib.prof_enable(False)
+    # the interpreter's cyclic GC otherwise fires a ~15 ms full collection every few steps (measured: tools/step_jitter.py);
+    # freezing the start-up object graph is the usual serving-process setting
+    gc.collect()
+    gc.freeze()
     cdist.barrier()
     torch.cuda.synchronize()
-    _lib.prof_enable(True)
+    if survey:
+        dominant = max((k for k in survey if k in ROOFLINE_KERNELS), key=lambda k: survey[k][0])
+        _lib.prof_enable_only(dominant)
+    else:
+        _lib.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -111,6 +139,7 @@ def main():
     prof = _lib.prof_read()
     _lib.prof_enable(False)
     dt = cdist.max_over_ranks(dt)
+    table, table_steps = (survey, n_survey) if survey else (prof, args.steps)
 
     if rank != 0:
         cdist.finalize()
@@ -118,10 +147,13 @@ def main():
     ms_step = dt / args.steps * 1e3
     pairs_s = B * world * args.steps / dt
     work = algorithmic_work(cfg)
-    kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps} for k, v in prof.items()}
+    kernels = {k: {"ms_per_step": round(v[0] / table_steps, 4), "launches_per_step": v[1] // table_steps} for k, v in table.items()}
     # ---- roofline of the dominant kernel (largest share of the step), from the HIP events recorded on the launch stream
     N0 = cfg.hw8[0] * cfg.hw8[1]
     fine_bytes = 4 * cfg.coarse_dim * (3 * (N0 + N0 // 4) + N0 + N0 // 4 + N0 // 16)  # q,k,v of both fine levels + acc in/out
+    N4 = cfg.hw4[0] * cfg.hw4[1]
+    proj_flops = (2 * cfg.coarse_layers * 4 * 2 * N0 * cfg.coarse_dim ** 2
+                  + 2 * cfg.cascade_cross_layers * 4 * 2 * N4 * cfg.cascade_dim ** 2)   # per pair, callers mode only
     per_launch = {  # kernel -> (bound, algorithmic work per launch for B pairs, unit, formula)
         "ds_gemm_kernel": ("mfma", work["coarse_flops"] * B, "flop", "2*L*S*C*B"),
         "quad_attn_kernel<fine>": ("hbm", fine_bytes * B / 2, "B", "4*C*(3*(N0+N1)+N0+N1+N2)*B / 2 launches (levels 1 and 0 averaged)"),
@@ -129,6 +161,8 @@ def main():
         "window_match_kernel": ("hbm", work["match_bytes"] * B / 2, "B", "(8*N*C + 12*N*K + 12*N)*B per direction"),
         "ds_conf_kernel": ("hbm", 4.0 * N0 * N0 * B, "B", "4*L*S*B (one read of the similarity matrix)"),
         "nchw_to_tokens_kernel": ("hbm", None, "B", "8*B*C*HW per tensor"),
+        "linear_nt_kernel": ("mfma", proj_flops * B / 32 if cfg.callers else None, "flop",
+                             "sum over the step's 32 launches of nprob*2*M*N*K, / 32 (12 x (3+1) coarse C=256, 4 x (3+1) cascade C=128)"),
     }
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
@@ -146,7 +180,7 @@ def main():
             "work_per_launch": f"{wk:.4e} {unit} = {formula}"}
     # every hot kernel against its own roof, for the record
     roofs = {}
-    for k, (ms, n) in prof.items():
+    for k, (ms, n) in table.items():
         if k in per_launch and per_launch[k][1]:
             bd, wk2, _, _ = per_launch[k]
             a2 = wk2 / (ms / n * 1e-3) / (1e12 if bd == "mfma" else 1e9)
@@ -163,10 +197,15 @@ def main():
                                f"(BASELINE.json configs[1]); 12 QTAttB + dual-softmax + 4 CascadeQTAttB + cascade matching + NMS per pair",
                    "pairs_per_gpu": B, "conf_matrix_materialized": bool(cfg.materialize_conf),
                    "qkv_memory_format": "channels_last" if args.channels_last else "contiguous (NCHW)",
+                   "entry": ("QuadtreeAttention / CascadeQuadtreeAttention on tokens (+ q/k/v/out projections, pyramid; "
+                             "section 8 f.1 workload, 90.7 GFLOP/pair of projections added)") if args.with_callers
+                            else "QTAttB / CascadeQTAttB on given q/k/v (section 8 d)",
                    "matches_last_step": int(res["n_total"]) if res is not None else None, "parallelism": f"pairs sharded over {world} GPU(s)"},
         "roofline": roof, "rooflines_all": roofs, "chain": chain, "kernels": kernels,
+        "kernels_measured_over": (f"last {n_survey} warm-up step(s), every kernel timed; the timed region times only the "
+                                  f"roofline kernel") if survey else "the timed region",
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.with_callers:
         cb, _ = cpu_baseline(cfg, inp)
         line["cpu_baseline"] = cb
         line["gpu_over_cpu"] = round(pairs_s / cb["value"], 1)

@@ -38,15 +38,24 @@ SIGNATURES = {
     "casmtr_nms_select_fwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _I, _I, _F, _I, _P, _I, _P,
                                    _P, _P, _P, _P, _P] + [_I] * 5 + [_P]),
     "casmtr_nms_select_ws_bytes": (_SZ, [_I] * 3),
+    "casmtr_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "casmtr_token_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_prof_enable": (None, [_I]),
+    "casmtr_prof_enable_only": (_I, [_I]),
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
 }
-PROF_COUNT = 13
+PROF_COUNT = 15
 
 
 def prof_enable(on: bool):
     lib().casmtr_prof_enable(int(on))
+
+
+def prof_enable_only(name: str):
+    """Time only the kernel called `name` (as reported by prof_read)."""
+    ids = {lib().casmtr_prof_name(i).decode(): i for i in range(PROF_COUNT)}
+    check(lib().casmtr_prof_enable_only(ids[name]), "prof_enable_only")
 
 
 def prof_read():

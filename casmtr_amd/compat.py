@@ -63,12 +63,14 @@ def _ensure_parents(full):
                 setattr(sys.modules[".".join(parts[: i - 1])], parts[i - 1], p)
 
 
-def install(packages: bool = True, matching: bool = True):
+def install(packages: bool = True, matching: bool = True, blocks: bool = True):
     """Register the three extension names.  packages=True also aliases the reference's QuadTreeAttention python
     modules (so src/model/modules/quadtree_attention.py:6 picks up the fused QTAttB / CascadeQTAttB); matching=True
     aliases src.model.functions.{coarse_matching,cascade_matching,post_processing} (imported by
-    src/model/cascade_model_stage3.py) to the fused matchers.  src.model.functions.cascade_functions is left alone:
-    the reference's own file keeps working because it only needs `fast_score_computation`."""
+    src/model/cascade_model_stage3.py) to the fused matchers; blocks=True aliases src.model.modules.quadtree_attention
+    (QuadtreeAttention / CascadeQuadtreeAttention, imported at src/model/modules/transformer.py:12) to the token-major
+    callers.  src.model.functions.cascade_functions is left alone: the reference's own file keeps working because it
+    only needs `fast_score_computation`."""
     for name, mod in extension_modules().items():
         sys.modules[name] = mod
     aliases = {}
@@ -82,8 +84,12 @@ def install(packages: bool = True, matching: bool = True):
         aliases["src.model.functions.coarse_matching"] = coarse_matching
         aliases["src.model.functions.cascade_matching"] = cascade_matching
         aliases["src.model.functions.post_processing"] = post_processing
+    if blocks:
+        from .modules import quadtree_block
+        aliases["src.model.modules.quadtree_attention"] = quadtree_block
+    for full, mod in aliases.items():   # leaves first: a parent package imported below must already see them
+        sys.modules[full] = mod
     for full, mod in aliases.items():
         _ensure_parents(full)
-        sys.modules[full] = mod
         parent = sys.modules[full.rsplit(".", 1)[0]]
         setattr(parent, full.rsplit(".", 1)[1], mod)

@@ -5,14 +5,14 @@
 #include "../../include/casmtr_hip.h"
 
 namespace casmtr {
-static bool g_on = false;
+static unsigned g_mask = 0;   // bit id set: kernel id is being timed
 struct Pair { hipEvent_t a, b; };
 static std::vector<Pair> g_ev[CASMTR_PROF_COUNT];
 static std::vector<Pair> g_free;
 static Pair g_open[CASMTR_PROF_COUNT];
 
 void prof_begin(int id, hipStream_t s) {
-    if (!g_on) return;
+    if (!(g_mask >> id & 1u)) return;
     Pair p;
     if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
     else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
@@ -20,7 +20,7 @@ void prof_begin(int id, hipStream_t s) {
     g_open[id] = p;
 }
 void prof_end(int id, hipStream_t s) {
-    if (!g_on) return;
+    if (!(g_mask >> id & 1u)) return;
     (void)hipEventRecord(g_open[id].b, s);
     g_ev[id].push_back(g_open[id]);
 }
@@ -31,14 +31,22 @@ using namespace casmtr;
 static const char* kNames[CASMTR_PROF_COUNT] = {
     "ds_gemm_kernel", "ds_reduce_kernel", "ds_conf_kernel", "ds_select", "coarse_logits_kernel", "coarse_row_kernel",
     "coarse_av_kernel", "quad_attn_kernel<fine>", "quad_attn_kernel<cascade>", "window_match_kernel", "nms_select",
-    "nchw_to_tokens_kernel", "window_warp_idx_kernel"};
+    "nchw_to_tokens_kernel", "window_warp_idx_kernel", "linear_nt_kernel", "token_pool_kernel"};
 
-extern "C" void casmtr_prof_enable(int on) {
+static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {
         for (auto& p : g_ev[i]) g_free.push_back(p);
         g_ev[i].clear();
     }
-    g_on = on != 0;
+    g_mask = mask;
+}
+
+extern "C" void casmtr_prof_enable(int on) { prof_reset(on ? ~0u : 0u); }
+
+extern "C" int casmtr_prof_enable_only(int id) {
+    if (id < 0 || id >= CASMTR_PROF_COUNT) return 1;
+    prof_reset(1u << id);
+    return 0;
 }
 
 extern "C" int casmtr_prof_read(int id, double* total_ms, int* count) {

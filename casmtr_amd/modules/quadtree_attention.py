@@ -146,25 +146,37 @@ class QTAttB(nn.Module):
         return cached[1]
 
     def _forward_fused(self, queries, keys, values):
-        n = len(queries)
-        weight = self._level_weights()
-        acc = prev_idx = None
         # one launch converts all 3 levels x (q,k,v) to token-major rows
         flat = [t.float() for lvl in zip(reversed(queries), reversed(keys), reversed(values)) for t in lvl]
         toks = ops.nchw_to_tokens_multi(flat)
-        for i, (query, key) in enumerate(zip(reversed(queries), reversed(keys))):
-            B, C, h0, w0 = query.shape
-            h1, w1 = key.shape[2:]
-            q, k, v = toks[3 * i:3 * i + 3]
+        n = len(queries)
+        return self._fused_levels([toks[3 * i:3 * i + 3] for i in range(n)],
+                                  [tuple(q.shape[2:]) for q in reversed(queries)],
+                                  [tuple(k.shape[2:]) for k in reversed(keys)])
+
+    def _fused_levels(self, levels, hw_q, hw_k):
+        """levels: [(q,k,v)] of token-major [B,L,C] tensors, COARSEST first; hw_q / hw_k the matching grid sizes."""
+        n = len(levels)
+        weight = self._level_weights()
+        acc = prev_idx = None
+        for i, (q, k, v) in enumerate(levels):
             if i == 0:
                 out = ops.qta_coarse_level(q, k, v, self.nhead, self.topks[0], w_level=weight[0], want_message=False)
             else:
                 # the reference computes top-k at the finest level too and throws it away (:219-227): skipped here
                 topk = self.topks[i] if i < n - 1 else 0
-                out = ops.qta_fine_level(q, k, v, prev_idx, (h0, w0), (h1, w1), self.nhead, topk, w_level=weight[i],
+                out = ops.qta_fine_level(q, k, v, prev_idx, hw_q[i], hw_k[i], self.nhead, topk, w_level=weight[i],
                                          acc_in=acc, want_message=False)
             acc, prev_idx = out["acc"], out["topk_idx"]
         return acc
+
+    def forward_tokens(self, queries, keys, values, hw_q, hw_k):
+        """Token-major entry point (no reference counterpart; used by casmtr_amd.modules.quadtree_block): pyramids of
+        [N, h_i*w_i, C] tensors, finest first, with their grid sizes -> message [N, H*W, nhead, dim].  Inference only."""
+        if self.lepe or _needs_autograd(self.weight, *queries, *keys, *values):
+            raise RuntimeError("QTAttB.forward_tokens is the inference path (no lepe, no autograd): use forward()")
+        lv = list(zip(reversed(queries), reversed(keys), reversed(values)))
+        return self._fused_levels(lv, list(reversed(hw_q)), list(reversed(hw_k)))
 
     def forward(self, queries, keys, values, q_mask=None, kv_mask=None, rel_pos=None):
         """queries/keys/values: pyramids of [N,C,H,W], finest first -> message [N, H*W, nhead, dim]  (:231-286).
@@ -286,8 +298,12 @@ class CascadeQTAttB(nn.Module):
         [N,HW,4*KW]  (modules/quadtree_attention.py:400-452)."""
         if _needs_autograd(query, key, value, rel_pos):
             return self._forward_composed(query, key, value, topk_pos, rel_pos)
-        h0, w0 = query.shape[2:]
-        h1, w1 = key.shape[2:]
         q, k, v = ops.nchw_to_tokens_multi([t.float() for t in (query, key, value)])
+        return self.forward_tokens(q, k, v, tuple(query.shape[2:]), tuple(key.shape[2:]), topk_pos, rel_pos)
+
+    def forward_tokens(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None):
+        """Token-major entry point: q [N,h0*w0,C], k/v [N,h1*w1,C].  Inference only."""
+        if _needs_autograd(q, k, v, rel_pos):
+            raise RuntimeError("CascadeQTAttB.forward_tokens is the inference path: use forward() for autograd")
         rp = None if rel_pos is None else rel_pos.contiguous().float()
-        return ops.cascade_attn(q, k, v, topk_pos.contiguous(), (h0, w0), (h1, w1), self.nhead, self.dilated, rp)
+        return ops.cascade_attn(q, k, v, topk_pos.contiguous(), tuple(hw_q), tuple(hw_k), self.nhead, self.dilated, rp)

@@ -1,0 +1,157 @@
+"""QuadtreeAttention / CascadeQuadtreeAttention: the modules that CALL QTAttB / CascadeQTAttB.
+
+Drop-in for src/model/modules/quadtree_attention.py: same constructor arguments, same forward signatures, same
+state-dict keys (`q_proj.weight`, `k_proj.weight`, `v_proj.weight` [C,C,1,1], `py_att.weight` / `cross_attn.*`,
+`proj.weight`, `proj.bias`).
+
+The reference takes [B,N,C] tokens, permutes them to NCHW (+ contiguous), applies three 1x1 convolutions, builds the
+avg-pool pyramid in NCHW, and QTAttB turns every level back into tokens.  The inference path here never leaves the token
+layout: one batched fp32-MFMA GEMM launch for the three projections, one pooling launch per pyramid level for q/k/v
+together, the fused level kernels on those buffers, one GEMM for the output projection.  No layout kernel runs at all.
+
+With autograd (training), `attn_type` 'A' / 'Guided', `lepe` or a QTAttB `rel_pos`, forward() keeps the reference's
+structure on torch ops + the composed attention modules.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .quadtree_attention import CascadeQTAttB, QTAttA, QTAttB, QTAttGuided, _needs_autograd
+
+
+def _init_weights(m):
+    """src/model/modules/quadtree_attention.py:50-66 (timm's trunc_normal_ == torch.nn.init.trunc_normal_)."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+    elif isinstance(m, nn.Conv2d):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        m.init = True  # QuadtreeBlock._init_weights skips modules carrying this flag (transformer.py:176-177)
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+def _project_qkv(mod, x, target):
+    """q_proj(x), k_proj(target), v_proj(target) on tokens, one launch."""
+    ws = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
+    bs = [mod.q_proj.bias, mod.k_proj.bias, mod.v_proj.bias]
+    if x.shape == target.shape:
+        return ops.linear_multi([x, target, target], [w.detach().float() for w in ws],
+                                [None if b is None else b.detach().float() for b in bs])
+    # different token counts (H,W != H1,W1): the query projection is its own problem shape
+    q = ops.linear(x, ws[0].detach().float(), None if bs[0] is None else bs[0].detach().float())
+    k, v = ops.linear_multi([target, target], [w.detach().float() for w in ws[1:]],
+                            [None if b is None else b.detach().float() for b in bs[1:]])
+    return q, k, v
+
+
+class QuadtreeAttention(nn.Module):
+    def __init__(self, dim, num_heads, topks, value_branch=False, act=nn.GELU(), qkv_bias=False, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, scale=1, attn_type="B"):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim = dim
+        self.num_heads = num_heads
+        self.q_proj = nn.Conv2d(dim, dim, kernel_size=1, stride=1, bias=qkv_bias)
+        self.k_proj = nn.Conv2d(dim, dim, kernel_size=1, stride=1, bias=qkv_bias)
+        self.v_proj = nn.Conv2d(dim, dim, kernel_size=1, stride=1, bias=qkv_bias)
+        self.attn_type = attn_type
+        if attn_type == "Guided":
+            self.py_att = QTAttGuided(num_heads, dim // num_heads, scale=scale, topks=topks)
+        elif attn_type == "A":
+            self.py_att = QTAttA(num_heads, dim // num_heads, scale=scale, topks=topks)
+        else:
+            self.py_att = QTAttB(num_heads, dim // num_heads, scale=scale, topks=topks)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.scale = scale
+        self.apply(_init_weights)
+
+    def _fused_ok(self, x, target, rel_pos):
+        return (self.attn_type not in ("A", "Guided") and rel_pos is None and x.is_cuda and not self.py_att.lepe
+                and not _needs_autograd(x, target, *self.parameters()))
+
+    def forward(self, x, target, H, W, H1=None, W1=None, rel_pos=None, topk_pos=None):
+        """x [B,H*W,C], target [B,H1*W1,C] -> [B,H*W,C]  (src/model/modules/quadtree_attention.py:68-100)."""
+        H1 = H if H1 is None else H1
+        W1 = W if W1 is None else W1
+        B, N, C = x.shape
+        if not self._fused_ok(x, target, rel_pos):
+            return self._forward_reference_structure(x, target, H, W, H1, W1, rel_pos, topk_pos)
+        q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
+        queries, keys, values, hw_q, hw_k = [], [], [], [], []
+        h, w, h1, w1 = H, W, H1, W1
+        for i in range(self.scale):
+            queries.append(q), keys.append(k), values.append(v)
+            hw_q.append((h, w)), hw_k.append((h1, w1))
+            if i != self.scale - 1:
+                if (h, w) == (h1, w1):
+                    q, k, v = ops.token_pool_multi([q, k, v], h, w)
+                else:
+                    (q,), (k, v) = ops.token_pool_multi([q], h, w), ops.token_pool_multi([k, v], h1, w1)
+                h, w, h1, w1 = h // 2, w // 2, h1 // 2, w1 // 2
+        msg = self.py_att.forward_tokens(queries, keys, values, hw_q, hw_k).view(B, -1, C)
+        out = ops.linear(msg, self.proj.weight.detach().float(),
+                         None if self.proj.bias is None else self.proj.bias.detach().float())
+        return self.proj_drop(out)
+
+    def _forward_reference_structure(self, x, target, H, W, H1, W1, rel_pos, topk_pos):
+        B, N, C = x.shape
+        x = x.permute(0, 2, 1).reshape(B, C, H, W).contiguous()
+        target = target.permute(0, 2, 1).reshape(B, C, H1, W1).contiguous()
+        q, k, v = self.q_proj(x), self.k_proj(target), self.v_proj(target)
+        queries, keys, values = [], [], []
+        for i in range(self.scale):
+            keys.append(k.float()), values.append(v.float()), queries.append(q.float())
+            if i != self.scale - 1:
+                k, q, v = (F.avg_pool2d(t, kernel_size=2, stride=2) for t in (k, q, v))
+        if self.attn_type == "Guided":
+            msg = self.py_att(queries, keys, values, rel_pos=rel_pos, topk_pos=topk_pos)
+        elif self.attn_type == "A":
+            msg = self.py_att(queries, keys, values)
+        else:
+            msg = self.py_att(queries, keys, values, rel_pos=rel_pos)
+        return self.proj_drop(self.proj(msg.reshape(B, -1, C).contiguous()))
+
+
+class CascadeQuadtreeAttention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, scale=2, dilated=1):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim = dim
+        self.num_heads = num_heads
+        self.q_proj = nn.Conv2d(dim, dim, kernel_size=1, stride=1, bias=qkv_bias)
+        self.k_proj = nn.Conv2d(dim, dim, kernel_size=1, stride=1, bias=qkv_bias)
+        self.v_proj = nn.Conv2d(dim, dim, kernel_size=1, stride=1, bias=qkv_bias)
+        self.cross_attn = CascadeQTAttB(num_heads, dim // num_heads, dilated=dilated)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.scale = scale
+        self.apply(_init_weights)
+
+    def forward(self, x, target, H, W, H1=None, W1=None, idx=None, rel_pos=None):
+        """x [B,H*W,C], target [B,H1*W1,C], idx [B,(H/2)(W/2),KW,2] -> (x' [B,H*W,C], upsampled_idx [B,H*W,4KW])
+        (src/model/modules/quadtree_attention.py:152-176)."""
+        H1 = H if H1 is None else H1
+        W1 = W if W1 is None else W1
+        B, N, C = x.shape
+        if rel_pos is not None:
+            rel_pos = rel_pos.to(torch.float32)
+        if x.is_cuda and not _needs_autograd(x, target, rel_pos, *self.parameters()):
+            q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
+            msg, upsampled_idx = self.cross_attn.forward_tokens(q, k, v, (H, W), (H1, W1), idx, rel_pos)
+            out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
+                             None if self.proj.bias is None else self.proj.bias.detach().float())
+            return self.proj_drop(out), upsampled_idx
+        x = x.permute(0, 2, 1).reshape(B, C, H, W).contiguous()
+        target = target.permute(0, 2, 1).reshape(B, C, H1, W1).contiguous()
+        q, k, v = self.q_proj(x), self.k_proj(target), self.v_proj(target)
+        msg, upsampled_idx = self.cross_attn(q.float(), k.float(), v.float(), idx, rel_pos)
+        return self.proj_drop(self.proj(msg.reshape(B, -1, C).contiguous())), upsampled_idx

@@ -160,6 +160,45 @@ def nchw_to_tokens_multi(xs):
     return outs
 
 
+def linear_multi(xs, ws, biases=None):
+    """y_i = x_i @ w_i^T (+ b_i) for up to 4 problems of one shape in one launch (k-ascending fp32 MFMA chain).
+    x_i [..., K] token-major, w_i [N, K] (a [N,K,1,1] conv weight is viewed), b_i [N] or None."""
+    import ctypes as C
+    n = len(xs)
+    biases = [None] * n if biases is None else list(biases)
+    xs = [_chk(x, "x") for x in xs]
+    ws = [_chk(w.reshape(w.shape[0], -1), "w") for w in ws]
+    bs = [_chk(b, "bias") for b in biases]
+    N, K = ws[0].shape
+    M = xs[0].numel() // K
+    if any(x.shape[-1] != K or x.numel() != M * K for x in xs) or any(tuple(w.shape) != (N, K) for w in ws):
+        raise RuntimeError("linear_multi: all problems must share (M, N, K)")
+    ys = [torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32) for x in xs]
+    arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    with torch.cuda.device(xs[0].device):
+        _lib.check(_lib.lib().casmtr_linear_fwd(arr(xs), arr(ws), arr(bs), arr(ys), n, M, N, K, _stream()), "linear_fwd")
+    return ys
+
+
+def linear(x, w, bias=None):
+    return linear_multi([x], [w], [bias])[0]
+
+
+def token_pool_multi(xs, H, W):
+    """avg_pool2d(2, 2) on token-major tensors: list of [B,H*W,C] -> list of [B,(H//2)*(W//2),C], one launch."""
+    import ctypes as C
+    n = len(xs)
+    xs = [_chk(x, "x") for x in xs]
+    B, HW, Cc = xs[0].shape
+    if HW != H * W or any(tuple(x.shape) != (B, HW, Cc) for x in xs):
+        raise RuntimeError("token_pool_multi: tensors must share the shape [B, H*W, C]")
+    ys = [torch.empty((B, (H // 2) * (W // 2), Cc), device=x.device, dtype=torch.float32) for x in xs]
+    arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    with torch.cuda.device(xs[0].device):
+        _lib.check(_lib.lib().casmtr_token_pool_fwd(arr(xs), arr(ys), n, B, H, W, Cc, _stream()), "token_pool_fwd")
+    return ys
+
+
 def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
     """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")

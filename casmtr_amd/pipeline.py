@@ -19,6 +19,7 @@ from . import ops
 from .matching.cascade_matching import CascadeMatching
 from .matching.coarse_matching import CoarseMatching
 from .modules.quadtree_attention import CascadeQTAttB, QTAttB
+from .modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention
 
 
 @dataclass
@@ -43,6 +44,8 @@ class HotPathConfig:
     cascade_temperature: float = 1.0
     nms_window: int = 5
     materialize_conf: bool = False    # data['stage_8c']['conf_matrix'] is not consumed at inference
+    callers: bool = False             # enter through QuadtreeAttention / CascadeQuadtreeAttention
+                                      # ([B,N,C] tokens in; q/k/v + output projections and the pyramid inside the step)
 
     @property
     def hw8(self):
@@ -87,6 +90,10 @@ def make_synthetic_inputs(cfg: HotPathConfig, B: int, device, seed: int = 0, cha
         for key in list(inp):
             v = inp[key]
             inp[key] = [t.contiguous(memory_format=torch.channels_last) for t in v] if isinstance(v, list) else v.contiguous(memory_format=torch.channels_last)
+    if cfg.callers:   # what LocalFeatureTransformer / CascadeFeatureTransformer hand to their attention blocks
+        for im in (0, 1):
+            inp[f"cx{im}"] = rn(B, h8 * w8, cfg.coarse_dim)
+            inp[f"fx{im}"] = rn(B, h4 * w4, cfg.cascade_dim)
     inp["weight"] = rn(3)
     inp["feat_8c0"] = rn(B, h8 * w8, cfg.coarse_dim)
     inp["feat_8c1"] = _warp_tokens(inp["feat_8c0"], (h8, w8), (3, 5), 0.35, g)
@@ -101,6 +108,21 @@ class HotPath(torch.nn.Module):
         self.cfg = cfg
         self.qta = QTAttB(cfg.coarse_heads, cfg.coarse_dim // cfg.coarse_heads, scale=3, topks=cfg.coarse_topks)
         self.cascade_qta = CascadeQTAttB(cfg.cascade_heads, cfg.cascade_dim // cfg.cascade_heads, dilated=1)
+        if cfg.callers:
+            g = torch.Generator().manual_seed(1234)
+
+            def unit_gain(m):   # random-init weights scaled so that q/k keep unit variance (trained-model-like softmaxes)
+                for lin in (m.q_proj, m.k_proj, m.v_proj, m.proj):
+                    with torch.no_grad():
+                        lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) / lin.weight.shape[1] ** 0.5)
+                return m
+
+            self.coarse_blocks = torch.nn.ModuleList(
+                unit_gain(QuadtreeAttention(cfg.coarse_dim, cfg.coarse_heads, cfg.coarse_topks, scale=3))
+                for _ in range(cfg.coarse_layers))
+            self.cascade_blocks = torch.nn.ModuleList(
+                unit_gain(CascadeQuadtreeAttention(cfg.cascade_dim, cfg.cascade_heads))
+                for _ in range(cfg.cascade_cross_layers))
         self.coarse_matching = CoarseMatching(
             {"thr": cfg.coarse_thr, "border_rm": cfg.coarse_border_rm, "train_coarse_percent": 0.3,
              "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.coarse_temperature},
@@ -128,7 +150,10 @@ class HotPath(torch.nn.Module):
             else:                # 'cross'
                 pairs = ((0, 1), (1, 0))
             for a, b in pairs:
-                msgs.append(self.qta(inp[f"cq{a}"], inp[f"ck{b}"], inp[f"cv{b}"]))
+                if cfg.callers:
+                    msgs.append(self.coarse_blocks[layer](inp[f"cx{a}"], inp[f"cx{b}"], h8, w8))
+                else:
+                    msgs.append(self.qta(inp[f"cq{a}"], inp[f"ck{b}"], inp[f"cv{b}"]))
         # 2. coarse matching
         self.coarse_matching(inp["feat_8c0"], inp["feat_8c1"], data, level="8c")
         st8 = data["stage_8c"]
@@ -137,9 +162,13 @@ class HotPath(torch.nn.Module):
         tp10 = ops.window_warp_idx(st8["next_idx_c10"], h8, w8, cfg.window_size)
         # 4. cascade cross attention
         idx01 = idx10 = None
-        for _ in range(cfg.cascade_cross_layers):
-            m0, idx01 = self.cascade_qta(inp["fq0"], inp["fk1"], inp["fv1"], tp01, None)
-            m1, idx10 = self.cascade_qta(inp["fq1"], inp["fk0"], inp["fv0"], tp10, None)
+        for layer in range(cfg.cascade_cross_layers):
+            if cfg.callers:
+                m0, idx01 = self.cascade_blocks[layer](inp["fx0"], inp["fx1"], h4, w4, idx=tp01)
+                m1, idx10 = self.cascade_blocks[layer](inp["fx1"], inp["fx0"], h4, w4, idx=tp10)
+            else:
+                m0, idx01 = self.cascade_qta(inp["fq0"], inp["fk1"], inp["fv1"], tp01, None)
+                m1, idx10 = self.cascade_qta(inp["fq1"], inp["fk0"], inp["fv0"], tp10, None)
             msgs += [m0, m1]
         # 5. cascade matching (+ NMS / selection)
         self.cascade_matching(inp["feat_4c0"], inp["feat_4c1"], idx01, idx10, data, level="4c", pre_level="8c")

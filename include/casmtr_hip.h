@@ -137,17 +137,38 @@ int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* next_idx01, c
 size_t casmtr_nms_select_ws_bytes(int B, int H0, int W0);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Callers of the attention kernels, token-major: QuadtreeAttention /
+ * CascadeQuadtreeAttention (src/model/modules/quadtree_attention.py:9-100,103-176) without the NCHW round trip.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* y_p[M,N] = x_p[M,K] . w_p[N,K]^T (+ bias_p[N]) for p < nprob <= 4 problems of one shape in ONE launch: the 1x1
+ * q_proj / k_proj / v_proj convolutions (quadtree_attention.py:31-33,79-81,158-160; weight [N,K,1,1] viewed as [N,K])
+ * and the output nn.Linear (:44,98,168).  fp32 MFMA, k-ascending fmaf chain, bias added after the chain.
+ * x/w/bias/y are HOST arrays of device pointers; bias (or any bias[p]) may be NULL.  K % 32 == 0.                */
+int casmtr_linear_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
+                      int nprob, int M, int N, int K, casmtr_stream_t stream);
+
+/* F.avg_pool2d(kernel_size=2, stride=2) of the pyramid loop (quadtree_attention.py:82-90) on token-major tensors:
+ * src_i [B,H,W,C] -> dst_i [B,H/2,W/2,C] for i < n <= 4 tensors in one launch (odd H/W: last row/column dropped,
+ * as torch does).  Window sum in (row, col) order, then * 0.25.  C % 4 == 0.                                      */
+int casmtr_token_pool_fwd(const float* const* src, float* const* dst, int n, int B, int H, int W, int C,
+                          casmtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart): per-kernel launch durations from HIP events recorded on the
  * launch stream.  Off by default.  casmtr_prof_enable(1) starts a fresh collection; casmtr_prof_read() waits for
  * the recorded events and returns the summed duration (ms) and the number of launches of kernel `id`.
+ * Each timed launch costs two event records on the stream (~3 us of serialisation each on MI355X).
  * ---------------------------------------------------------------------------------------------------------- */
 enum {
     CASMTR_PROF_DS_GEMM = 0, CASMTR_PROF_DS_REDUCE, CASMTR_PROF_DS_CONF, CASMTR_PROF_DS_SELECT,
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
-    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_COUNT
+    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
+/* fresh collection that times ONLY kernel `id` (two event records per launch of that kernel, none for the others) */
+int casmtr_prof_enable_only(int id);
 int casmtr_prof_read(int id, double* total_ms, int* count);
 const char* casmtr_prof_name(int id);
 

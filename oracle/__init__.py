@@ -254,3 +254,52 @@ def window_warp_idx(idx, H, W, ws=5):
     out = np.empty((B, N, ws * ws, 2), np.int64)
     lib().orc_window_warp_idx(_p(idx), _p(out), *_ci(B, N, H, W, ws))
     return out
+
+
+# ------------------------------------------------------------------------------- §8(f)-1: the callers, token-major
+def linear(x, w, bias=None):
+    """y[..., n] = chain_k fmaf(x[..., k], w[n, k]) (+ bias[n]): nn.Conv2d(dim, dim, 1) on tokens / nn.Linear
+    (src/model/modules/quadtree_attention.py:79-81,98)."""
+    x, w, bias = _f(x), _f(w), _f(bias)
+    N, K = w.shape[0], int(np.prod(w.shape[1:]))
+    M = x.size // K
+    y = np.empty(x.shape[:-1] + (N,), np.float32)
+    lib().orc_linear(_p(x), _p(w), _p(bias), _p(y), C.c_int64(M), *_ci(N, K))
+    return y
+
+
+def token_pool(x, H, W):
+    """avg_pool2d(kernel 2, stride 2) of a token-major [B,H*W,C] tensor -> [B,(H//2)*(W//2),C] (:86-90)."""
+    x = _f(x)
+    B, _, Cc = x.shape
+    out = np.empty((B, (H // 2) * (W // 2), Cc), np.float32)
+    lib().orc_token_pool(_p(x), _p(out), *_ci(B, H, W, Cc))
+    return out
+
+
+def _nchw(t, h, w):
+    B, _, Cc = t.shape
+    return np.ascontiguousarray(t.reshape(B, h, w, Cc).transpose(0, 3, 1, 2))
+
+
+def quadtree_attention_block(x, target, hw, hw1, wq, wk, wv, level_weight, wp, bp, nhead, topks, scale=3,
+                             bq=None, bk=None, bv=None):
+    """QuadtreeAttention.forward with attn_type 'B' (src/model/modules/quadtree_attention.py:68-100):
+    x [B,N,C] / target [B,N1,C] tokens -> ([B,N,C], QTAttB per-level dicts)."""
+    q, k, v = linear(x, wq, bq), linear(target, wk, bk), linear(target, wv, bv)
+    (h, w), (h1, w1) = hw, hw1
+    qs, ks, vs = [], [], []
+    for i in range(scale):
+        qs.append(_nchw(q, h, w)); ks.append(_nchw(k, h1, w1)); vs.append(_nchw(v, h1, w1))
+        if i != scale - 1:
+            q, k, v = token_pool(q, h, w), token_pool(k, h1, w1), token_pool(v, h1, w1)
+            h, w, h1, w1 = h // 2, w // 2, h1 // 2, w1 // 2
+    msg, levels = qtattb_forward(qs, ks, vs, level_weight, nhead, topks)
+    return linear(msg.reshape(x.shape[0], -1, x.shape[2]), wp, bp), levels
+
+
+def cascade_quadtree_attention_block(x, target, hw, hw1, idx, wq, wk, wv, wp, bp, nhead, dilated=1, rel_pos=None):
+    """CascadeQuadtreeAttention.forward (:152-176) -> (x [B,N,C], upsampled_idx [B,N,4*KW])."""
+    q, k, v = linear(x, wq), linear(target, wk), linear(target, wv)
+    msg, up = cascade_attn(q, k, v, idx, hw, hw1, nhead, dilated, rel_pos)
+    return linear(msg, wp, bp), up

@@ -233,6 +233,39 @@ def gen_cascade_attn():
         save("cascade_attn_" + name, checksum=checksum(inp), topk_pos=topk_pos, message=msg, upsampled_idx=up)
 
 
+def gen_quadtree_block():
+    """§8 f.1: the reference's QuadtreeAttention / CascadeQuadtreeAttention (src/model/modules/quadtree_attention.py)."""
+    from src.model.modules import quadtree_attention as blk
+    for name, cfg in CASES["quadtree_block"].items():
+        inp = make_inputs("quadtree_block", name)
+        C = cfg["nhead"] * cfg["D"]
+        bias = bool(cfg.get("qkv_bias"))
+        if cfg["kind"] == "qta":
+            m = blk.QuadtreeAttention(C, cfg["nhead"], cfg["topks"], qkv_bias=bias, scale=3, attn_type="B")
+        else:
+            m = blk.CascadeQuadtreeAttention(C, cfg["nhead"], qkv_bias=bias)
+        with torch.no_grad():
+            for n, conv in (("q", m.q_proj), ("k", m.k_proj), ("v", m.v_proj)):
+                conv.weight.copy_(T(inp["w" + n]).view(C, C, 1, 1))
+                if bias:
+                    conv.bias.copy_(T(inp["b" + n]))
+            m.proj.weight.copy_(T(inp["wp"]))
+            m.proj.bias.copy_(T(inp["bp"]))
+            if cfg["kind"] == "qta":
+                m.py_att.weight.copy_(T(inp["weight"]))
+                (h, w), (h1, w1) = cfg["hw"], cfg.get("hw1", cfg["hw"])
+                rec = _record_levels(m.py_att)
+                out = m(T(inp["x"]), T(inp["target"]), h, w, h1, w1)
+                extra = {f"L{lv}_topk_idx": r[3].to(torch.int16) for lv, r in enumerate(rec)}
+                save("quadtree_block_" + name, checksum=checksum(inp), out=out, **extra)
+            else:
+                hc, wc = cfg["coarse_hw"]
+                ns = types.SimpleNamespace(window=window_offsets(cfg["ws"]), full_window=None)
+                topk_pos, _ = CascadeFeatureTransformer.get_window_warp_idx(ns, T(inp["coarse_idx"]), cfg["B"], hc, wc)
+                out, up = m(T(inp["x"]), T(inp["target"]), hc * 2, wc * 2, idx=topk_pos)
+                save("quadtree_block_" + name, checksum=checksum(inp), out=out, upsampled_idx=up, topk_pos=topk_pos)
+
+
 def match_config(cfg):
     return {"thr": cfg.get("thr", 0.2), "border_rm": cfg.get("border_rm", 0), "train_coarse_percent": 0.3,
             "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.get("T", 0.1)}
@@ -302,6 +335,7 @@ def gen_cascade_matching():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "qtattb", "qtatt_variants", "cascade_attn", "coarse_matching", "cascade_matching"]
+    which = sys.argv[1:] or ["ops", "qtattb", "qtatt_variants", "cascade_attn", "coarse_matching", "cascade_matching",
+                              "quadtree_block"]
     for w in which:
         globals()["gen_" + w]()

@@ -28,6 +28,16 @@ CASES = {
         "c12x20_relpos": dict(seed=32, B=1, coarse_hw=(12, 20), nhead=4, D=32, ws=5, rel_pos=True),
         "c8_h2": dict(seed=33, B=1, coarse_hw=(8, 8), nhead=2, D=32, ws=5),
     },
+    # §8 f.1: the callers QuadtreeAttention / CascadeQuadtreeAttention on [B,N,C] tokens.  `exact`: activations and
+    # projection weights on a dyadic grid coarse enough that every partial sum of the q/k/v projections is exactly
+    # representable -- the reference's BLAS and the k-ordered chain then agree bit for bit whatever their summation order.
+    "quadtree_block": {
+        "qa_g16_exact": dict(seed=71, kind="qta", B=2, hw=(16, 16), nhead=4, D=32, topks=[8, 4, 2], exact=True),
+        "qa_g32x24_cross_bias": dict(seed=72, kind="qta", B=1, hw=(32, 24), hw1=(24, 32), nhead=4, D=32, topks=[8, 4, 2],
+                                     exact=True, qkv_bias=True),
+        "qa_g16_randn": dict(seed=73, kind="qta", B=1, hw=(16, 16), nhead=8, D=32, topks=[8, 4, 2], exact=False),
+        "cqa_c8_exact": dict(seed=74, kind="cqa", B=2, coarse_hw=(8, 8), nhead=4, D=32, ws=5, exact=True),
+    },
     "coarse_matching": {
         "g24": dict(seed=41, B=2, hw0=(24, 24), hw1=(24, 24), C=256),
         "g16_conf": dict(seed=44, B=1, hw0=(16, 16), hw1=(16, 16), C=256, store_conf=True),
@@ -119,6 +129,29 @@ def make_inputs(group, name):
                    coarse_idx=r.integers(0, hc * wc, (B, hc * wc), dtype=np.int64))
         if cfg.get("rel_pos"):
             out["rel_pos"] = _randn(r, B, H, h * w, 4 * cfg["ws"] ** 2)
+        return out
+    if group == "quadtree_block":
+        H, D, B = cfg["nhead"], cfg["D"], cfg["B"]
+        C = H * D
+        if cfg["kind"] == "qta":
+            (h, w), (h1, w1) = cfg["hw"], cfg.get("hw1", cfg["hw"])
+        else:
+            h = h1 = cfg["coarse_hw"][0] * 2
+            w = w1 = cfg["coarse_hw"][1] * 2
+        dy = (lambda a, s, q: np.round(a * s) / q) if cfg["exact"] else (lambda a, s, q: a * (s / q))
+        out = dict(x=dy(_randn(r, B, h * w, C), 4, 8).astype(np.float32),
+                   target=dy(_randn(r, B, h1 * w1, C), 4, 8).astype(np.float32),
+                   wq=dy(_randn(r, C, C), 4, 16).astype(np.float32), wk=dy(_randn(r, C, C), 4, 16).astype(np.float32),
+                   wv=dy(_randn(r, C, C), 4, 16).astype(np.float32), wp=(_randn(r, C, C) / np.sqrt(C)).astype(np.float32),
+                   bp=_randn(r, C) * np.float32(0.1))
+        if cfg.get("qkv_bias"):
+            for n in ("bq", "bk", "bv"):
+                out[n] = dy(_randn(r, C), 4, 8).astype(np.float32)
+        if cfg["kind"] == "qta":
+            out["weight"] = _randn(r, 3)
+        else:
+            hc, wc = cfg["coarse_hw"]
+            out["coarse_idx"] = r.integers(0, hc * wc, (B, hc * wc), dtype=np.int64)
         return out
     if group == "coarse_matching":
         f0, f1 = _warped_features(r, cfg["B"], cfg["hw0"], cfg["hw1"], cfg["C"])

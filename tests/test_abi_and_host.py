@@ -143,3 +143,16 @@ def test_valid_extents_and_border_masks():
     idx[0, 3, 3] = torch.tensor([0, 3])   # target row 0 < b
     out = mask_window_border(mask, idx, 2, False, 6, 8)
     assert not out[0, 3, 3] and out[0, 2, 2] and not out[0, 0, 4] and not out[0, 3, 7]
+
+
+def test_compat_aliases_block_module():
+    import sys
+    import casmtr_amd.compat as compat
+    compat.install()
+    mod = sys.modules["src.model.modules.quadtree_attention"]
+    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention
+    assert mod.QuadtreeAttention is QuadtreeAttention and mod.CascadeQuadtreeAttention is CascadeQuadtreeAttention
+    m = QuadtreeAttention(64, 2, [8, 4, 2], scale=3)
+    assert sorted(m.state_dict()) == sorted(["q_proj.weight", "k_proj.weight", "v_proj.weight", "py_att.weight",
+                                             "proj.weight", "proj.bias"])
+    assert tuple(m.q_proj.weight.shape) == (64, 64, 1, 1)

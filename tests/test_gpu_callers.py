@@ -1,0 +1,148 @@
+"""GPU: SURVEY.md §8 f.1 -- the callers of the attention kernels (QuadtreeAttention / CascadeQuadtreeAttention) and the two
+kernels they add (token-major projection GEMM, token pyramid pooling): bit-exact against the oracle, within fp32
+tolerance of the reference-python fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_inputs import CASES, make_inputs
+from parity_utils import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("M,Nn,K,nprob,bias", [(300, 256, 256, 3, False), (130, 64, 64, 1, True), (1024, 128, 128, 2, True),
+                                               (257, 200, 96, 4, True)])
+def test_linear_bit_exact(M, Nn, K, nprob, bias):
+    from casmtr_amd import ops
+    r = np.random.default_rng(M + Nn)
+    xs = [r.standard_normal((M, K)).astype(np.float32) for _ in range(nprob)]
+    ws = [r.standard_normal((Nn, K)).astype(np.float32) for _ in range(nprob)]
+    bs = [r.standard_normal(Nn).astype(np.float32) if bias and i != 1 else None for i in range(nprob)]
+    ys = ops.linear_multi([T(x) for x in xs], [T(w) for w in ws], [None if b is None else T(b) for b in bs])
+    for x, w, b, y in zip(xs, ws, bs, ys):
+        assert np.array_equal(N(y), oracle.linear(x, w, b)), "projection GEMM differs from the k-ordered fmaf chain"
+
+
+def test_linear_contract_errors():
+    from casmtr_amd import ops
+    x, w = torch.zeros(4, 48, device=DEV), torch.zeros(8, 48, device=DEV)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.linear(x, w)                      # K % 32 != 0
+    with pytest.raises(RuntimeError):
+        ops.linear(x.cpu(), w)                # host tensor: no CPU fallback
+
+
+@pytest.mark.parametrize("B,h,w,C,n", [(2, 12, 10, 16, 3), (1, 7, 9, 8, 1), (2, 26, 26, 256, 3)])
+def test_token_pool_bit_exact(B, h, w, C, n):
+    from casmtr_amd import ops
+    r = np.random.default_rng(h * w)
+    xs = [r.standard_normal((B, h * w, C)).astype(np.float32) for _ in range(n)]
+    ys = ops.token_pool_multi([T(x) for x in xs], h, w)
+    for x, y in zip(xs, ys):
+        assert np.array_equal(N(y), oracle.token_pool(x, h, w))
+
+
+def _load_weights(m, inp, C, bias):
+    with torch.no_grad():
+        for n, conv in (("q", m.q_proj), ("k", m.k_proj), ("v", m.v_proj)):
+            conv.weight.copy_(T(inp["w" + n]).view(C, C, 1, 1))
+            if bias:
+                conv.bias.copy_(T(inp["b" + n]))
+        m.proj.weight.copy_(T(inp["wp"]))
+        m.proj.bias.copy_(T(inp["bp"]))
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES["quadtree_block"].items() if c["kind"] == "qta"])
+def test_quadtree_attention_block(name):
+    from casmtr_amd.modules.quadtree_block import QuadtreeAttention
+    cfg = CASES["quadtree_block"][name]
+    inp, g = make_inputs("quadtree_block", name), load_golden("quadtree_block", name)
+    C, bias = cfg["nhead"] * cfg["D"], bool(cfg.get("qkv_bias"))
+    (h, w), (h1, w1) = cfg["hw"], cfg.get("hw1", cfg["hw"])
+    m = QuadtreeAttention(C, cfg["nhead"], cfg["topks"], qkv_bias=bias, scale=3, attn_type="B").to(DEV).eval()
+    _load_weights(m, inp, C, bias)
+    with torch.no_grad():
+        m.py_att.weight.copy_(T(inp["weight"]))
+        out = m(T(inp["x"]), T(inp["target"]), h, w, h1, w1)
+    ref, _ = oracle.quadtree_attention_block(inp["x"], inp["target"], (h, w), (h1, w1), inp["wq"], inp["wk"], inp["wv"],
+                                             inp["weight"], inp["wp"], inp["bp"], cfg["nhead"], cfg["topks"], 3,
+                                             inp.get("bq"), inp.get("bk"), inp.get("bv"))
+    # projections, pooling and the level selection are bit-exact; the messages carry __expf-level differences
+    assert_close(N(out), ref, 2e-5, "fused block vs oracle")
+    assert_close(N(out), g["out"], TOL, "fused block vs reference python")
+    # training / autograd: the reference's structure on torch ops + the composed attention
+    x = T(inp["x"]).requires_grad_(True)
+    out2 = m(x, T(inp["target"]), h, w, h1, w1)
+    assert_close(N(out2), g["out"], TOL, "reference-structure path vs reference python")
+    out2.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and m.q_proj.weight.grad is not None
+
+
+def test_cascade_quadtree_attention_block():
+    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention
+    name = "cqa_c8_exact"
+    cfg = CASES["quadtree_block"][name]
+    inp, g = make_inputs("quadtree_block", name), load_golden("quadtree_block", name)
+    C = cfg["nhead"] * cfg["D"]
+    hc, wc = cfg["coarse_hw"]
+    m = CascadeQuadtreeAttention(C, cfg["nhead"]).to(DEV).eval()
+    _load_weights(m, inp, C, False)
+    tp = T(g["topk_pos"].astype(np.int64))
+    with torch.no_grad():
+        out, up = m(T(inp["x"]), T(inp["target"]), 2 * hc, 2 * wc, idx=tp)
+    assert np.array_equal(N(up), g["upsampled_idx"].astype(np.int64))
+    assert_close(N(out), g["out"], TOL, "fused cascade block vs reference python")
+    ref, up_o = oracle.cascade_quadtree_attention_block(inp["x"], inp["target"], (2 * hc, 2 * wc), (2 * hc, 2 * wc),
+                                                        g["topk_pos"].astype(np.int64), inp["wq"], inp["wk"], inp["wv"],
+                                                        inp["wp"], inp["bp"], cfg["nhead"])
+    assert np.array_equal(N(up), up_o)
+    assert_close(N(out), ref, 2e-5, "fused cascade block vs oracle")
+    x = T(inp["x"]).requires_grad_(True)
+    out2, up2 = m(x, T(inp["target"]), 2 * hc, 2 * wc, idx=tp)
+    assert np.array_equal(N(up2), g["upsampled_idx"].astype(np.int64))
+    assert_close(N(out2), g["out"], TOL, "reference-structure path vs reference python")
+    out2.sum().backward()
+    assert torch.isfinite(x.grad).all()
+
+
+def test_block_full_size_levels_bit_exact():
+    """BASELINE size (104x104 tokens, C=256, topks 32/16/8): q/k/v projections + pyramid + three attention levels on the
+    GPU select exactly the oracle's neighbours; the block output agrees to fp32 round-off."""
+    from casmtr_amd import ops
+    from casmtr_amd.modules.quadtree_block import QuadtreeAttention
+    r = np.random.default_rng(2024)
+    B, h, w, C, H = 1, 104, 104, 256, 8
+    x = r.standard_normal((B, h * w, C)).astype(np.float32)
+    tgt = r.standard_normal((B, h * w, C)).astype(np.float32)
+    m = QuadtreeAttention(C, H, [32, 16, 8], scale=3).to(DEV).eval()
+    with torch.no_grad():   # unit-variance q/k so that the softmaxes are neither flat nor one-hot
+        for conv in (m.q_proj, m.k_proj, m.v_proj):
+            conv.weight.copy_(torch.randn(C, C, 1, 1, generator=torch.Generator().manual_seed(1)) / C ** 0.5)
+        m.proj.weight.copy_(torch.randn(C, C, generator=torch.Generator().manual_seed(2)) / C ** 0.5)
+        out = m(T(x), T(tgt), h, w)
+        # level-by-level index parity through the ops the block runs
+        q, k, v = ops.linear_multi([T(x), T(tgt), T(tgt)], [m.q_proj.weight, m.k_proj.weight, m.v_proj.weight])
+    wq, wk, wv = (N(c.weight).reshape(C, C) for c in (m.q_proj, m.k_proj, m.v_proj))
+    assert np.array_equal(N(q), oracle.linear(x, wq)) and np.array_equal(N(v), oracle.linear(tgt, wv))
+    ref, levels = oracle.quadtree_attention_block(x, tgt, (h, w), (h, w), wq, wk, wv, N(m.py_att.weight), N(m.proj.weight),
+                                                  N(m.proj.bias), H, [32, 16, 8], 3)
+    with torch.no_grad():
+        q1, k1, v1 = ops.token_pool_multi([q, k, v], h, w)
+        q2, k2, v2 = ops.token_pool_multi([q1, k1, v1], h // 2, w // 2)
+        l0 = ops.qta_coarse_level(q2, k2, v2, H, 32)
+        l1 = ops.qta_fine_level(q1, k1, v1, l0["topk_idx"], (52, 52), (52, 52), H, 16)
+    assert np.array_equal(N(l0["topk_idx"]), levels[0]["topk_idx"])
+    assert np.array_equal(N(l1["topk_idx"]), levels[1]["topk_idx"])
+    assert_close(N(out), ref, 2e-5, "full-size block vs oracle")

@@ -96,6 +96,46 @@ def test_cascade_attn(name):
     assert_close(msg, g["message"], SOFTMAX_TOL, "message")
 
 
+@pytest.mark.parametrize("name", list(CASES["quadtree_block"]))
+def test_quadtree_block(name):
+    """§8 f.1 callers: projections + pyramid + attention + output projection against the reference's modules."""
+    inp, g = _inputs("quadtree_block", name)
+    cfg = CASES["quadtree_block"][name]
+    if cfg["kind"] == "qta":
+        hw, hw1 = cfg["hw"], cfg.get("hw1", cfg["hw"])
+        out, levels = oracle.quadtree_attention_block(
+            inp["x"], inp["target"], hw, hw1, inp["wq"], inp["wk"], inp["wv"], inp["weight"], inp["wp"], inp["bp"],
+            cfg["nhead"], cfg["topks"], 3, inp.get("bq"), inp.get("bk"), inp.get("bv"))
+        n_bad = 0
+        for lv, o in enumerate(levels):
+            n_bad += _audit_topk(o["topk_idx"], g[f"L{lv}_topk_idx"].astype(np.int64), o["topk_score"])
+        if cfg["exact"]:  # q/k/v are exact in both implementations: the attention sees identical inputs
+            assert n_bad == 0
+        if n_bad == 0:
+            assert_close(out, g["out"], SOFTMAX_TOL, "block output")
+    else:
+        hc, wc = cfg["coarse_hw"]
+        tp = oracle.window_warp_idx(inp["coarse_idx"], hc, wc, cfg["ws"])
+        assert np.array_equal(tp, g["topk_pos"].astype(np.int64))
+        out, up = oracle.cascade_quadtree_attention_block(
+            inp["x"], inp["target"], (2 * hc, 2 * wc), (2 * hc, 2 * wc), tp, inp["wq"], inp["wk"], inp["wv"], inp["wp"],
+            inp["bp"], cfg["nhead"])
+        assert np.array_equal(up, g["upsampled_idx"].astype(np.int64))
+        assert_close(out, g["out"], SOFTMAX_TOL, "block output")
+
+
+def test_token_pool_is_torch_avg_pool2d():
+    """the pooling order is ATen's: bit-exact against F.avg_pool2d on CPU, odd sizes included"""
+    import torch
+    import torch.nn.functional as F
+    r = np.random.default_rng(5)
+    for (h, w, c) in ((12, 10, 16), (7, 9, 8)):
+        x = r.standard_normal((2, h * w, c)).astype(np.float32)
+        t = torch.from_numpy(x).view(2, h, w, c).permute(0, 3, 1, 2).contiguous()
+        ref = F.avg_pool2d(t, kernel_size=2, stride=2).permute(0, 2, 3, 1).reshape(2, -1, c).numpy()
+        assert np.array_equal(oracle.token_pool(x, h, w), ref)
+
+
 def _check_matches(o, g, conf_tol_ok):
     so, sg = match_set(o["b_ids"], o["i_ids"], o["j_ids"]), match_set(g["b_ids"], g["i_ids"], g["j_ids"])
     for extra in (so ^ sg):
