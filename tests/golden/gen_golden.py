@@ -30,11 +30,10 @@ from golden_inputs import CASES, make_inputs, checksum  # noqa: E402  (tests/gol
 
 
 # ------------------------------------------------------------------------------------------------ stubs
-def _stub(name, **attrs):
-    m = types.ModuleType(name)
-    m.__dict__.update(attrs)
-    sys.modules[name] = m
-    return m
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402  (third-party stand-ins: kornia / timm / yacs ...)
+
+_stub = ref_stubs.stub
 
 
 def install_stubs():
@@ -42,33 +41,7 @@ def install_stubs():
     _stub("score_computation_cuda")
     _stub("value_aggregation_cuda")
     _stub("fast_score_computation")
-    k = _stub("kornia")
-    kf = _stub("kornia.feature")
-    kf.__all__ = []
-    k.feature = kf
-    ku = _stub("kornia.utils")
-    kug = _stub("kornia.utils.grid")
-
-    def create_meshgrid(h, w, normalized_coordinates=True, device=None, dtype=torch.float32):
-        ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=dtype), torch.arange(w, device=device, dtype=dtype),
-                                indexing="ij")
-        return torch.stack([xs, ys], -1)[None]
-
-    kug.create_meshgrid = create_meshgrid
-    ku.grid = kug
-    ku.create_meshgrid = create_meshgrid
-    k.utils = ku
-    _stub("timm")
-    _stub("timm.models")
-    tl = _stub("timm.models.layers")
-
-    class DropPath(nn.Identity):
-        def __init__(self, *a, **k):
-            super().__init__()
-
-    tl.DropPath = DropPath
-    tl.to_2tuple = lambda x: (x, x) if not isinstance(x, (tuple, list)) else tuple(x)
-    tl.trunc_normal_ = lambda t, std=1.0, **k: nn.init.trunc_normal_(t, std=std)
+    ref_stubs.install_third_party()
 
 
 install_stubs()

@@ -27,63 +27,9 @@ import gen_golden as gg  # noqa: E402  installs the extension / kornia / timm st
 REF = gg.REF
 
 
-class CN(dict):
-    """the sliver of yacs.config.CfgNode that configs/default.py and the model config file use"""
-    def __init__(self, d=None):
-        super().__init__()
+import ref_stubs  # noqa: E402
 
-    def __getattr__(self, k):
-        try:
-            return self[k]
-        except KeyError:
-            raise AttributeError(k)
-
-    def __setattr__(self, k, v):
-        self[k] = v
-
-    def clone(self):
-        return copy.deepcopy(self)
-
-    def merge_from_file(self, path):
-        spec = importlib.util.spec_from_file_location("cfgfile", path)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-
-        def upd(a, b):
-            for k, v in b.items():
-                if isinstance(v, CN) and isinstance(a.get(k), CN):
-                    upd(a[k], v)
-                else:
-                    a[k] = copy.deepcopy(v)
-        upd(self, mod.cfg)
-
-
-def more_stubs():
-    y = gg._stub("yacs")
-    y.config = gg._stub("yacs.config", CfgNode=CN)
-    k = sys.modules["kornia"]
-    kg, kgs, kgd = gg._stub("kornia.geometry"), gg._stub("kornia.geometry.subpix"), gg._stub("kornia.geometry.subpix.dsnt")
-    mesh = sys.modules["kornia.utils.grid"].create_meshgrid
-
-    def spatial_expectation2d(inp, normalized_coordinates=True):
-        b, c, h, w = inp.shape
-        if normalized_coordinates:
-            xs, ys = torch.linspace(-1, 1, w), torch.linspace(-1, 1, h)
-        else:
-            xs, ys = torch.arange(w).float(), torch.arange(h).float()
-        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
-        x = inp.view(b, c, -1)
-        return torch.stack([(x * gx.reshape(-1)).sum(-1), (x * gy.reshape(-1)).sum(-1)], -1)
-
-    kgd.spatial_expectation2d = spatial_expectation2d
-    kgs.dsnt, kg.subpix, k.geometry = kgd, kgs, kg
-    for n in ("cv2", "h5py"):
-        gg._stub(n)
-    gg._stub("loguru", logger=types.SimpleNamespace(info=print, warning=print, error=print, debug=print))
-
-
-def lower(c):
-    return {k.lower(): lower(v) for k, v in c.items()} if isinstance(c, CN) else c
+CN, lower, more_stubs = ref_stubs.CN, ref_stubs.lower, ref_stubs.install_full_model_extras
 
 
 def load_pair(hw=(192, 256)):
