@@ -32,6 +32,12 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
 }
 
+// Same, but lanes whose source falls outside the row read 0 (bound_ctrl): no `old` operand to materialise.
+template <int CTRL>
+__device__ __forceinline__ float dpp_zfill_f32(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+
 // All-lanes max / sum over each 16-lane DPP row (4 independent rows per wave).
 __device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
     v = max(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]

@@ -179,12 +179,21 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
     // so every load instruction covers 8 whole cache lines (a lane-per-row walk touches 64 lines per instruction and is
     // bound by the L1/TA rate).  The sequential fmaf chain over d then runs as an 8-lane systolic array: lane p owns
     // d = 4p..4p+3 of its group's 8 rows; a row's accumulator enters at lane 0 and is handed from lane p to lane p+1 with
-    // a DPP row_shr:1, so the arithmetic is exactly the reference's d-ascending chain.  A 3-stage register barrel rotation
-    // (by the lane's piece index) skews the rows so that every lane uses the same register slot in the same step.
+    // a DPP shift, so the arithmetic is exactly the reference's d-ascending chain.  The two groups of a 16-lane DPP row are
+    // interleaved (even lanes / odd lanes): the hand-over is row_shr:2 with zero fill, which gives both piece-0 lanes the
+    // chain's initial 0 for free (adjacent groups + row_shr:1 needed a v_mov 0 and a v_cndmask per child and step).
+    // A 3-stage register barrel rotation (by the lane's piece index) skews the rows so that every lane uses the same
+    // register slot in the same step.
     if (MODE == 0) for (int p = wave; p < H * PPH; p += 4) {
         const int h = p / PPH;
         const int kb0 = (p % PPH) * 64;
+#ifdef SYSTOLIC_ADJ
         const int g = lane >> 3, pc = lane & 7;
+        const unsigned long long startm = 0x0101010101010101ull;   // lanes with pc == 0
+        const float zero = 0.f;
+#else
+        const int g = ((lane >> 4) << 1) | (lane & 1), pc = (lane >> 1) & 7;
+#endif
         const int* cb = cand + (MODE == 0 ? h * CS : 0);
         const float* kbase = a.key + (size_t)b * S * HD + h * 32 + pc * 4;
         f32x4 v[8];
@@ -212,8 +221,15 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
             const f32x4 kv = v[t & 7];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                float in = dpp_f32<0x111>(acc[f]);          // row_shr:1 -> the accumulator lane p-1 produced in step t-1
-                in = pc == 0 ? 0.f : in;                     // a chain starts at piece 0
+#ifdef SYSTOLIC_ADJ
+                float in;
+                asm("s_mov_b64 vcc, %3\n\ts_nop 1\n\tv_cndmask_b32_dpp %0, %1, %2, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    : "=v"(in) : "v"(acc[f]), "v"(zero), "s"(startm) : "vcc");
+#else
+                float in = dpp_zfill_f32<0x112>(acc[f]);    // row_shr:2
+#endif
+                // -> the accumulator piece p-1 produced in step t-1;
+                                                             // piece 0 (lanes 0,1 of the row) reads 0: a chain starts there
                 in = __builtin_fmaf(qv[f].x, kv.x, in);
                 in = __builtin_fmaf(qv[f].y, kv.y, in);
                 in = __builtin_fmaf(qv[f].z, kv.z, in);

@@ -2,7 +2,8 @@
 match gather, + optional cProfile of the enqueue (--cprofile)."""
 import cProfile, pstats, sys, time, io
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from casmtr_amd import _lib, dist as cdist
 from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
 

@@ -1,7 +1,8 @@
 """Per-step wall time over many steps, with allocator / GC counters, to find where step-time spikes come from."""
 import gc, sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
 
 cfg = HotPathConfig(callers="--with-callers" in sys.argv)
