@@ -187,13 +187,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
     if (MODE == 0) for (int p = wave; p < H * PPH; p += 4) {
         const int h = p / PPH;
         const int kb0 = (p % PPH) * 64;
-#ifdef SYSTOLIC_ADJ
-        const int g = lane >> 3, pc = lane & 7;
-        const unsigned long long startm = 0x0101010101010101ull;   // lanes with pc == 0
-        const float zero = 0.f;
-#else
         const int g = ((lane >> 4) << 1) | (lane & 1), pc = (lane >> 1) & 7;
-#endif
         const int* cb = cand + (MODE == 0 ? h * CS : 0);
         const float* kbase = a.key + (size_t)b * S * HD + h * 32 + pc * 4;
         f32x4 v[8];
@@ -221,14 +215,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 6 : 4)) void quad_attn_kernel(con
             const f32x4 kv = v[t & 7];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-#ifdef SYSTOLIC_ADJ
-                float in;
-                asm("s_mov_b64 vcc, %3\n\ts_nop 1\n\tv_cndmask_b32_dpp %0, %1, %2, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                    : "=v"(in) : "v"(acc[f]), "v"(zero), "s"(startm) : "vcc");
-#else
-                float in = dpp_zfill_f32<0x112>(acc[f]);    // row_shr:2
-#endif
-                // -> the accumulator piece p-1 produced in step t-1;
+                float in = dpp_zfill_f32<0x112>(acc[f]);    // row_shr:2 -> the accumulator piece p-1 produced in step t-1;
                                                              // piece 0 (lanes 0,1 of the row) reads 0: a chain starts there
                 in = __builtin_fmaf(qv[f].x, kv.x, in);
                 in = __builtin_fmaf(qv[f].y, kv.y, in);
