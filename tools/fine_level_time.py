@@ -23,4 +23,4 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n
 tl1 = t(lambda: ops.qta_fine_level(q1, k1, v1, l0["topk_idx"], (52, 52), (52, 52), H, 16, w_level=0.3, acc_in=l0["acc"], want_message=False))
 tl0 = t(lambda: ops.qta_fine_level(q0, k0, v0, idx1, (104, 104), (104, 104), H, 0, w_level=0.4, acc_in=l1["acc"], want_message=False))
-print(f"STOP={os.environ.get('CASMTR_QUAD_STOP', '0')} AFF={os.environ.get('CASMTR_QUAD_AFF', '0')}  K=128 launch {tl1*1e3:.1f} us   K=64 launch {tl0*1e3:.1f} us")
+print(f"STOP={os.environ.get('CASMTR_QUAD_STOP', '0')} VAR={os.environ.get('CASMTR_QUAD_VAR', '0')}  K=128 launch {tl1*1e3:.1f} us   K=64 launch {tl0*1e3:.1f} us")
