@@ -605,9 +605,8 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
                                                                 int w, int nquads) {
     constexpr int KM = 128, RP = 36, NCH = C / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                                        // [2][KM][RP]
-    int* cidx = reinterpret_cast<int*>(smem + 2 * KM * RP);    // [4][KM]
-    int& differ = cidx[4 * KM];
+    float* tile = smem;                                        // [2][K][RP]  (K rows, not KM: one more workgroup per CU)
+    int* cidx = reinterpret_cast<int*>(smem + 2 * K * RP);     // [4][KM]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -616,22 +615,17 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
     int tok[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) tok[f] = (2 * qy + (f >> 1)) * w + 2 * qx + (f & 1);
-    if (tid == 0) differ = 0;
     for (int e = tid; e < 4 * K; e += 256) {
         const int f = e / K, k = e % K;
         cidx[f * KM + k] = (int)idx[((size_t)b * N + tok[f]) * K + k];
     }
     __syncthreads();
-    {
-        bool d = false;
-        for (int e = tid; e < 3 * K; e += 256) {
-            const int f = 1 + e / K, k = e % K;
-            if (cidx[f * KM + k] != cidx[k]) d = true;
-        }
-        if (d) differ = 1;
+    bool d = false;
+    for (int e = tid; e < 3 * K; e += 256) {
+        const int f = 1 + e / K, k = e % K;
+        if (cidx[f * KM + k] != cidx[k]) d = true;
     }
-    __syncthreads();
-    const bool shared_rows = differ == 0;
+    const bool shared_rows = __syncthreads_or(d) == 0;
     const int rounds = shared_rows ? 1 : 4;
     const float* kb = fk + (size_t)b * M * C;
     // staging map: thread -> (row r0 + 32*i, float4 q4 of the 32-channel chunk)
@@ -658,7 +652,7 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
                     f32x4 o;
                     o.x = div_scalar<RECIP>(pre[i].x, sqrtC, inv_sqrtC); o.y = div_scalar<RECIP>(pre[i].y, sqrtC, inv_sqrtC);
                     o.z = div_scalar<RECIP>(pre[i].z, sqrtC, inv_sqrtC); o.w = div_scalar<RECIP>(pre[i].w, sqrtC, inv_sqrtC);
-                    *reinterpret_cast<f32x4*>(tile + (buf * KM + r) * RP + q4 * 4) = o;
+                    *reinterpret_cast<f32x4*>(tile + (buf * K + r) * RP + q4 * 4) = o;
                 }
             }
         };
@@ -677,7 +671,7 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
                 for (int p = 0; p < 2; ++p) {
                     const int k = p * 64 + lane;
                     if (k < K) {
-                        const f32x4* rp = reinterpret_cast<const f32x4*>(tile + ((ch & 1) * KM + k) * RP);
+                        const f32x4* rp = reinterpret_cast<const f32x4*>(tile + ((ch & 1) * K + k) * RP);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const f32x4 kv = rp[i];
@@ -736,7 +730,7 @@ static int launch_window_match_r(const float* fq, const float* fk, const int64_t
     const float sqrtC = (float)sqrt((double)C);
     ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
     if (h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N) {
-        const size_t lds = sizeof(float) * (2 * 128 * 36 + 4 * 128 + 4);
+        const size_t lds = sizeof(float) * (2 * K * 36 + 4 * 128);
         const int nquads = (h / 2) * (w / 2);
         hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3(nquads, B), dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC,
                            1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, h, w, nquads);
