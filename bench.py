@@ -174,10 +174,21 @@ def main():
         ach, peak, u = wk / (avg_ms * 1e-3) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
     else:
         ach, peak, u = wk / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
+    # what the gather kernels really pull on: 128-byte key / value rows out of L2 / Infinity Fabric.  The chip's ceiling for
+    # that pattern depends on the working set per XCD (tools/probes/gather_bw.hip: 29 TB/s L2-resident, 12 at 11 MB, 9.3 at 22 MB)
+    gather = None
+    if dname == "quad_attn_kernel<fine>":
+        tk = cfg.coarse_topks
+        gbytes = 2 * 128 * cfg.coarse_heads * ((N0 // 16) * 4 * tk[0] + (N0 // 4) * 4 * tk[1]) * B / 2
+        gather = {"gathered_row_bytes_per_launch": gbytes, "achieved_TBps": round(gbytes / (avg_ms * 1e-3) / 1e12, 2),
+                  "ceiling_TBps_at_this_working_set": 9.3, "working_set_per_xcd_MB": round(2 * N0 * cfg.coarse_dim * 4 / 1e6, 1),
+                  "source": "tools/probes/gather_bw.hip (DESIGN.md section 8)"}
     roof = {"kernel": dname, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
             "traffic": pmc.get(dname, {}).get("hbm_bytes_per_launch"), "avg_launch_ms": round(avg_ms, 4),
             "launches_per_step": dn // args.steps, "share_of_step": round(dms / args.steps / ms_step, 3),
             "work_per_launch": f"{wk:.4e} {unit} = {formula}"}
+    if gather:
+        roof["l2_gather"] = gather
     # every hot kernel against its own roof, for the record
     roofs = {}
     for k, (ms, n) in table.items():

@@ -14,7 +14,8 @@ BENCH_NAME = [("quad_attn_kernel<8, 64, 0>", "quad_attn_kernel<fine>"), ("quad_a
               ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("window_match", "window_match_kernel"),
               ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
               ("nchw_to_tokens_kernel", "nchw_to_tokens_kernel"), ("coarse_row_kernel", "coarse_row_kernel"),
-              ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel")]
+              ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel"),
+              ("linear_nt_kernel", "linear_nt_kernel"), ("token_pool_kernel", "token_pool_kernel")]
 
 
 def per_kernel(path, counter):
