@@ -12,12 +12,17 @@ import torch
 import torch.distributed as dist
 
 
+# CASMTR_FORCE_DIST=1: initialise the process group and run every collective even with a single rank -- lets a 1-GPU box
+# exercise the RCCL code path (tests/test_gpu_dist_nccl.py); two ranks cannot share one device under RCCL.
+_FORCE = os.environ.get("CASMTR_FORCE_DIST", "0") == "1"
+
+
 def init_from_env(backend=None):
     """-> (rank, world, local_rank); initialises the default group when WORLD_SIZE > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -29,7 +34,7 @@ def init_from_env(backend=None):
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def barrier():
