@@ -251,3 +251,58 @@ def test_contract_errors(ops):
         ops.qta_score_fwd(q.transpose(1, 2), key, idx)   # not contiguous (score_computation.cpp:7)
     with pytest.raises(RuntimeError):
         ops.qta_score_fwd(q, key, idx.int())            # index dtype
+
+
+@pytest.mark.parametrize("H,Kp,topk", [(4, 40, 24), (2, 64, 16), (8, 33, 8)])
+def test_fine_level_wide_candidate_lists(ops, H, Kp, topk):
+    """K = 4*Kp in (128, 256]: the KMAX = 256 instantiations (4 systolic passes per head), every head count -- bit-exact top-k"""
+    r = np.random.default_rng(100 * H + Kp)
+    B, (h0, w0), (h1, w1) = 2, (12, 16), (24, 16)
+    C = H * 32
+    q = r.standard_normal((B, h0 * w0, C)).astype(np.float32)
+    k = r.standard_normal((B, h1 * w1, C)).astype(np.float32)
+    v = r.standard_normal((B, h1 * w1, C)).astype(np.float32)
+    Lq, Sp = (h0 // 2) * (w0 // 2), (h1 // 2) * (w1 // 2)
+    prev = np.stack([np.stack([r.permutation(Sp)[:Kp] for _ in range(H)], -1) for _ in range(B * Lq)]).reshape(B, Lq, Kp, H)
+    acc_in = r.standard_normal((B, Lq, H, 32)).astype(np.float32)
+    o = oracle.qta_fine_level(q.reshape(B, -1, H, 32), k.reshape(B, -1, H, 32), v.reshape(B, -1, H, 32), prev, (h0, w0), (h1, w1),
+                              topk, 0.37, acc_in)
+    out = ops.qta_fine_level(T(q), T(k), T(v), T(prev.astype(np.int64)), (h0, w0), (h1, w1), H, topk, w_level=0.37, acc_in=T(acc_in))
+    assert np.array_equal(N(out["topk_idx"]), o["topk_idx"])
+    assert_close(N(out["topk_score"]), o["topk_score"], SOFTMAX_TOL, "topk_score")
+    assert_close(N(out["acc"]), o["acc"], SOFTMAX_TOL, "merged message")
+
+
+@pytest.mark.parametrize("H,ws", [(2, 7), (4, 7), (8, 3)])
+def test_cascade_attn_other_windows(ops, H, ws):
+    """window 7 -> K = 196 (KMAX = 256), window 3 -> K = 36 (KMAX = 64); heads 2 / 4 / 8; rel_pos on"""
+    r = np.random.default_rng(7 * H + ws)
+    B, hc, wc = 1, 10, 8
+    h, w, C = 2 * hc, 2 * wc, H * 32
+    q, k, v = (r.standard_normal((B, h * w, C)).astype(np.float32) for _ in range(3))
+    cidx = r.integers(0, hc * wc, (B, hc * wc))
+    tp = oracle.window_warp_idx(cidx, hc, wc, ws)
+    rel = r.standard_normal((B, H, h * w, 4 * ws * ws)).astype(np.float32)
+    mo, uo = oracle.cascade_attn(q, k, v, tp, (h, w), (h, w), H, rel_pos=rel)
+    tpg = ops.window_warp_idx(T(cidx.astype(np.int64)), hc, wc, ws)
+    assert np.array_equal(N(tpg), tp)
+    msg, up = ops.cascade_attn(T(q), T(k), T(v), tpg, (h, w), (h, w), H, rel_pos=T(rel))
+    assert np.array_equal(N(up), uo)
+    assert_close(N(msg), mo, 2e-5, "message vs oracle")
+
+
+def test_empty_batch_and_limits(ops):
+    """B = 0 returns empty tensors (no launch); shapes outside the kernels' envelope raise instead of falling back"""
+    z = lambda *s: torch.zeros(s, device=DEV)
+    out = ops.qta_coarse_level(z(0, 16, 64), z(0, 16, 64), z(0, 16, 64), 2, 4, w_level=1.0)
+    assert out["acc"].shape[0] == 0 and out["topk_idx"].shape == (0, 16, 4, 2)
+    f = ops.dual_softmax(z(0, 16, 32), z(0, 16, 32), (4, 4), (4, 4), 0.1, 0.2)
+    assert int(f["n"].item()) == 0 if "n" in f else True
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):   # odd grid side below a finer level (reference: view() would fail)
+        ops.qta_fine_level(z(1, 15, 64), z(1, 16, 64), z(1, 16, 64), torch.zeros((1, 3, 2, 2), device=DEV, dtype=torch.int64),
+                           (3, 5), (4, 4), 2, 2)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):   # more than 256 candidates per quad
+        ops.qta_fine_level(z(1, 16, 64), z(1, 1600, 64), z(1, 1600, 64), torch.zeros((1, 4, 80, 2), device=DEV, dtype=torch.int64),
+                           (4, 4), (40, 40), 2, 2)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):   # window list longer than 128
+        ops.window_match(z(1, 16, 64), z(1, 400, 64), torch.zeros((1, 16, 144), device=DEV, dtype=torch.int64))
