@@ -590,11 +590,14 @@ __global__ __launch_bounds__(256) void window_match_kernel(const float* __restri
     }
 }
 
-// Quad variant: one workgroup per quad of query tokens (the 4 children of a coarse cell).  CascadeQTAttB hands every
-// child the same window list (modules/quadtree_attention.py:450), so the K x C key tile is fetched, normalised and staged
-// in LDS ONCE per quad -- 32 channels at a time, double buffered: the loads of chunk c+1 are in flight while the 4 waves
-// (wave <-> child token, lane <-> candidate) extend their fmaf chains over chunk c.  The kernel verifies that the 4 index
-// rows really are identical; if not it walks the tokens one after the other through the same code (same results).
+// Quad variant: one WAVE per quad of query tokens (the 4 children of a coarse cell), 4 quads per workgroup, no block-level
+// synchronisation.  CascadeQTAttB hands every child the same window list (modules/quadtree_attention.py:450): lane <->
+// candidates k = lane and 64 + lane; each lane reads its candidate row's 32-channel chunk straight into registers
+// (8 x dwordx4), normalises it once and extends the chains of all 4 children with it, so a key row is fetched and normalised
+// once per quad.  The kernel verifies that the 4 index rows really are identical; if not, each child walks its own rows
+// (same results).  The 4 normalised queries sit in 2 KB of wave-private LDS and come back as broadcast reads.  Same
+// arithmetic as above: operands pre-scaled, c-ascending fmaf chain.  (An LDS-staged version -- key tile staged 32 channels at
+// a time, double buffered, wave <-> child -- needed 8 block barriers per quad and ran at 0.82 ms per launch against 0.56.)
 template <int C, bool RECIP>
 __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __restrict__ fq, const float* __restrict__ fk,
                                                                 const int64_t* __restrict__ idx,
@@ -603,122 +606,111 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
                                                                 float* __restrict__ conf, float* __restrict__ next_conf,
                                                                 int64_t* __restrict__ next_idx, int N, int M, int K, int h,
                                                                 int w, int nquads) {
-    constexpr int KM = 128, RP = 36, NCH = C / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                                        // [2][K][RP]  (K rows, not KM: one more workgroup per CU)
-    int* cidx = reinterpret_cast<int*>(smem + 2 * K * RP);     // [4][KM]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* qn = smem + wave * 4 * C;                              // [4 children][C] normalised queries
     const int b = blockIdx.y;
-    const int quad = xcd_chunk_remap(blockIdx.x, nquads);      // neighbouring quads (overlapping windows) share an L2
+    const int quad = xcd_chunk_remap(blockIdx.x, gridDim.x) * 4 + wave;   // neighbouring quads (overlapping windows) share an L2
+    if (quad >= nquads) return;
     const int wq = w >> 1, qy = quad / wq, qx = quad % wq;
     int tok[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) tok[f] = (2 * qy + (f >> 1)) * w + 2 * qx + (f & 1);
-    for (int e = tid; e < 4 * K; e += 256) {
-        const int f = e / K, k = e % K;
-        cidx[f * KM + k] = (int)idx[((size_t)b * N + tok[f]) * K + k];
-    }
-    __syncthreads();
-    bool d = false;
-    for (int e = tid; e < 3 * K; e += 256) {
-        const int f = 1 + e / K, k = e % K;
-        if (cidx[f * KM + k] != cidx[k]) d = true;
-    }
-    const bool shared_rows = __syncthreads_or(d) == 0;
-    const int rounds = shared_rows ? 1 : 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+        for (int c = lane; c < C; c += 64) qn[f * C + c] = div_scalar<RECIP>(fq[((size_t)b * N + tok[f]) * C + c], sqrtC, inv_sqrtC);
+    int ci[2][4];
+    bool lsame = true;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int k = p * 64 + lane;
+            ci[p][f] = k < K ? (int)idx[((size_t)b * N + tok[f]) * K + k] : 0;
+            lsame = lsame && ci[p][f] == ci[p][0];
+        }
+    const bool same = __ballot(!lsame) == 0ull;                  // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float* kb = fk + (size_t)b * M * C;
-    // staging map: thread -> (row r0 + 32*i, float4 q4 of the 32-channel chunk)
-    const int q4 = tid & 7, r0 = tid >> 3;
+    float acc[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[p][f] = 0.f;
+    const int rounds = same ? 1 : 4;
     for (int rd = 0; rd < rounds; ++rd) {
-        const int* cl = cidx + rd * KM;                        // the list being staged (everyone's when shared)
-        const bool mine = shared_rows || wave == rd;           // does this wave score against it?
-        const int n = tok[shared_rows ? wave : rd];
-        const cfloat_p qp = as_const(fq + ((size_t)b * N + n) * C);
-        float acc[2] = {0.f, 0.f};
-        f32x4 pre[4];
-        auto issue = [&](int ch) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + 32 * i;
-                if (r < K) pre[i] = *reinterpret_cast<const f32x4*>(kb + ((unsigned)cl[r] * (unsigned)C + (unsigned)(ch * 32 + q4 * 4)));
-            }
-        };
-        auto commit = [&](int buf) {
+        for (int ch = 0; ch < C / 32; ++ch) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + 32 * i;
-                if (r < K) {
-                    f32x4 o;
-                    o.x = div_scalar<RECIP>(pre[i].x, sqrtC, inv_sqrtC); o.y = div_scalar<RECIP>(pre[i].y, sqrtC, inv_sqrtC);
-                    o.z = div_scalar<RECIP>(pre[i].z, sqrtC, inv_sqrtC); o.w = div_scalar<RECIP>(pre[i].w, sqrtC, inv_sqrtC);
-                    *reinterpret_cast<f32x4*>(tile + (buf * K + r) * RP + q4 * 4) = o;
-                }
-            }
-        };
-        __syncthreads();   // previous round's readers are done with both buffers
-        issue(0);
-        commit(0);
-        __syncthreads();
+            for (int p = 0; p < 2; ++p) {
+                if (p * 64 < K) {  // wave-uniform
+                    int row = ci[p][0];
+                    if (!same) row = rd == 1 ? ci[p][1] : (rd == 2 ? ci[p][2] : (rd == 3 ? ci[p][3] : row));
+                    const f32x4* kp = reinterpret_cast<const f32x4*>(kb + (size_t)row * C + ch * 32);
+                    f32x4 kr[8];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (ch + 1 < NCH) issue(ch + 1);               // in flight underneath the chains below
-            if (mine) {
-                float qn[32];
+                    for (int i = 0; i < 8; ++i) kr[i] = kp[i];
 #pragma unroll
-                for (int i = 0; i < 32; ++i) qn[i] = div_scalar<RECIP>(qp[ch * 32 + i], sqrtC, inv_sqrtC);
+                    for (int i = 0; i < 8; ++i) {
+                        kr[i].x = div_scalar<RECIP>(kr[i].x, sqrtC, inv_sqrtC); kr[i].y = div_scalar<RECIP>(kr[i].y, sqrtC, inv_sqrtC);
+                        kr[i].z = div_scalar<RECIP>(kr[i].z, sqrtC, inv_sqrtC); kr[i].w = div_scalar<RECIP>(kr[i].w, sqrtC, inv_sqrtC);
+                    }
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int k = p * 64 + lane;
-                    if (k < K) {
-                        const f32x4* rp = reinterpret_cast<const f32x4*>(tile + ((ch & 1) * K + k) * RP);
+                    for (int f = 0; f < 4; ++f) {
+                        if (same || f == rd) {
+                            const f32x4* qp = reinterpret_cast<const f32x4*>(qn + f * C + ch * 32);   // broadcast reads
+                            float a = acc[p][f];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const f32x4 kv = rp[i];
-                            acc[p] = __builtin_fmaf(qn[4 * i + 0], kv.x, acc[p]);
-                            acc[p] = __builtin_fmaf(qn[4 * i + 1], kv.y, acc[p]);
-                            acc[p] = __builtin_fmaf(qn[4 * i + 2], kv.z, acc[p]);
-                            acc[p] = __builtin_fmaf(qn[4 * i + 3], kv.w, acc[p]);
+                            for (int i = 0; i < 8; ++i) {
+                                const f32x4 qv = qp[i];
+                                a = __builtin_fmaf(qv.x, kr[i].x, a);
+                                a = __builtin_fmaf(qv.y, kr[i].y, a);
+                                a = __builtin_fmaf(qv.z, kr[i].z, a);
+                                a = __builtin_fmaf(qv.w, kr[i].w, a);
+                            }
+                            acc[p][f] = a;
                         }
                     }
                 }
             }
-            if (ch + 1 < NCH) commit((ch + 1) & 1);         // the other buffer: nobody reads it during this chunk
-            __syncthreads();
         }
-        if (mine) {
-            const int* myc = cidx + (shared_rows ? 0 : rd) * KM;
-            const int c0 = lane < K ? myc[lane] : 0, c1 = 64 + lane < K ? myc[64 + lane] : 0;
-            const int mqv = mq ? mq[(size_t)b * N + n] : 1;
-            float x[2];
-            unsigned key[2];
+    }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int k = p * 64 + lane;
-                x[p] = 0.f; key[p] = 0u;
-                if (k < K) {
-                    float v = div_scalar<RECIP>(acc[p], T, invT);
-                    if (mq && !(mqv && mk[(size_t)b * M + (p ? c1 : c0)])) v = NEG_FILL;
-                    x[p] = v; key[p] = f2ord(v);
-                }
+    for (int f = 0; f < 4; ++f) {
+        const int n = tok[f];
+        const int c0 = ci[0][f], c1 = ci[1][f];
+        const int mqv = mq ? mq[(size_t)b * N + n] : 1;
+        float x[2];
+        unsigned key[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int k = p * 64 + lane;
+            x[p] = 0.f; key[p] = 0u;
+            if (k < K) {
+                float v = div_scalar<RECIP>(acc[p][f], T, invT);
+                if (mq && !(mqv && mk[(size_t)b * M + (p ? c1 : c0)])) v = NEG_FILL;
+                x[p] = v; key[p] = f2ord(v);
             }
-            const unsigned wm = wave_max_u32(max(key[0], key[1]));
-            const float m = ord2f(wm);
-            float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
-            float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
-            const float sm = wave_sum_f32(e0 + e1);
-            e0 = e0 / sm; e1 = e1 / sm;
-            if (conf) {
-                if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
-                if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
-            }
-            const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
-            const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
-            const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
-            if (lane == (am & 63)) {
-                next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
-                next_idx[(size_t)b * N + n] = am < 64 ? c0 : c1;
-            }
+        }
+        const unsigned wm = wave_max_u32(max(key[0], key[1]));
+        const float m = ord2f(wm);
+        float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
+        float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
+        const float sm = wave_sum_f32(e0 + e1);
+        e0 = e0 / sm; e1 = e1 / sm;
+        if (conf) {
+            if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
+            if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
+        }
+        const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
+        const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
+        const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+        if (lane == (am & 63)) {
+            next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
+            next_idx[(size_t)b * N + n] = am < 64 ? c0 : c1;
         }
     }
 }
@@ -730,10 +722,9 @@ static int launch_window_match_r(const float* fq, const float* fk, const int64_t
     const float sqrtC = (float)sqrt((double)C);
     ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
     if (h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N) {
-        const size_t lds = sizeof(float) * (2 * K * 36 + 4 * 128);
         const int nquads = (h / 2) * (w / 2);
-        hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3(nquads, B), dim3(256), lds, s, fq, fk, idx, mq, mk, sqrtC,
-                           1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, h, w, nquads);
+        hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3((nquads + 3) / 4, B), dim3(256), sizeof(float) * 16 * C, s, fq,
+                           fk, idx, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, h, w, nquads);
     } else {
         const size_t lds = sizeof(float) * 4 * (CASMTR_SLAB_FLOATS + 128);
         const int nblocks = (N + 3) / 4;
