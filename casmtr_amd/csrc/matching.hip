@@ -260,7 +260,11 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
 // through wave-uniform scalar loads, the column best lives in registers, the row best is a DPP wave reduction -> one
 // atomic per (row, wave).  No LDS, full occupancy, 1 KiB coalesced reads.
 #define DSC_ROWS 64
-__global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf) {
+// When conf_matrix is not materialised, only entries that can exceed `thr` matter downstream (conf > thr is tested first, and
+// a row / column maximum that takes part in a match is attained by such an entry): conf = p01 * p10 > thr needs p01 > thr,
+// i.e. sim > rmax + log(thr * rsum).  A (row, wave) pair none of whose 256 entries passes that test (minus a slack far above
+// the rounding of __expf) is skipped after 4 compares and a ballot -- almost all of them: the pass becomes a pure read.
+__global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf, float thr) {
     const int b = blockIdx.z, i0 = blockIdx.y * DSC_ROWS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -298,7 +302,12 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
         for (int q = 0; q < RU; ++q) {
             const int r = r0 + q;
             if (r >= nr) break;  // wave-uniform
-            const float rm = rmax[r], rinv = 1.0f / rsum[r];
+            const float rm = rmax[r], rs = rsum[r], rinv = 1.0f / rs;
+            if (!want_conf && thr > 0.f) {
+                const float tau = rm + __logf(thr * rs) - 1e-2f;   // wave-uniform
+                const bool any = x[q][0] > tau || x[q][1] > tau || x[q][2] > tau || x[q][3] > tau;
+                if (__ballot(any) == 0ull) continue;
+            }
             float cf[4];
             float rbest = -1.f; int rj = 0;
 #pragma unroll
@@ -493,7 +502,7 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     {
         ProfScope ps(CASMTR_PROF_DS_CONF, s);
         hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
-                           w, L, S, want_conf);
+                           w, L, S, want_conf, thr);
     }
     CASMTR_CHECK_LAUNCH();
     ProfScope ps(CASMTR_PROF_DS_SELECT, s);
