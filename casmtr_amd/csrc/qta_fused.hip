@@ -563,24 +563,30 @@ __global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict_
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int s0 = 0; s0 < Spad; s0 += 32) {
-        __syncthreads();
-        {   // P chunk: 128 rows x 32 cols ; thread -> (row = tid>>1, 16 cols)
-            const int row = tid >> 1, c0 = (tid & 1) * 16;
-            const int l = l0 + row;
+    // chunk s0 of P (128 x 32; thread -> row tid>>1, 16 columns) and V (32 x 32; thread -> row tid>>3, 4 columns) is fetched
+    // into registers while the MFMAs of chunk s0 - 32 run (the loop used to be load -> barrier -> MFMA -> barrier, and with
+    // 1.5 workgroups per CU nothing else covered the load latency)
+    const int prow = tid >> 1, pc0 = (tid & 1) * 16, pl = l0 + prow;
+    const int vr = tid >> 3, vc = (tid & 7) * 4;
+    const float* pbase = Pg + ((size_t)bh * L + (pl < L ? pl : L - 1)) * Spad + pc0;
+    f32x4 pp[4], vv;
+    auto fetch = [&](int s0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (l < L) p = *reinterpret_cast<const f32x4*>(Pg + ((size_t)bh * L + l) * Spad + s0 + c0 + 4 * i);
-                Ps[row][c0 + 4 * i + 0] = p.x; Ps[row][c0 + 4 * i + 1] = p.y;
-                Ps[row][c0 + 4 * i + 2] = p.z; Ps[row][c0 + 4 * i + 3] = p.w;
-            }
-            // V chunk: 32 rows x 32 cols ; thread -> (row = tid>>3, 4 cols)
-            const int vr = tid >> 3, vc = (tid & 7) * 4;
-            f32x4 vv = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (s0 + vr < S) vv = *reinterpret_cast<const f32x4*>(v + (((size_t)b * S + s0 + vr) * H + h) * 32 + vc);
-            Vs[vr][vc + 0] = vv.x; Vs[vr][vc + 1] = vv.y; Vs[vr][vc + 2] = vv.z; Vs[vr][vc + 3] = vv.w;
+        for (int i = 0; i < 4; ++i) pp[i] = *reinterpret_cast<const f32x4*>(pbase + s0 + 4 * i);
+        vv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s0 + vr < S) vv = *reinterpret_cast<const f32x4*>(v + (((size_t)b * S + s0 + vr) * H + h) * 32 + vc);
+    };
+    fetch(0);
+    for (int s0 = 0; s0 < Spad; s0 += 32) {
+        __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 p = pl < L ? pp[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            Ps[prow][pc0 + 4 * i + 0] = p.x; Ps[prow][pc0 + 4 * i + 1] = p.y;
+            Ps[prow][pc0 + 4 * i + 2] = p.z; Ps[prow][pc0 + 4 * i + 3] = p.w;
         }
+        Vs[vr][vc + 0] = vv.x; Vs[vr][vc + 1] = vv.y; Vs[vr][vc + 2] = vv.z; Vs[vr][vc + 3] = vv.w;
+        if (s0 + 32 < Spad) fetch(s0 + 32);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
