@@ -244,12 +244,16 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
     if (t >= total) return;
     const int b = t / N, i = t % N;
     const size_t base = (size_t)b * nblk * N + i;
-    float m = pm[base]; int am = pa[base];
+    // only ~1.3 workgroups per CU: the loads of 8 partials are issued together, the argmax is fetched once at the end
+    float m = pm[base]; int kb = 0;
+#pragma unroll 8
     for (int k = 1; k < nblk; ++k) {
         const float x = pm[base + (size_t)k * N];
-        if (x > m) { m = x; am = pa[base + (size_t)k * N]; }
+        if (x > m) { m = x; kb = k; }   // strict: the first block holding the maximum wins
     }
+    const int am = pa[base + (size_t)kb * N];
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nblk; ++k) s += ps[base + (size_t)k * N] * __expf(pm[base + (size_t)k * N] - m);
     omax[t] = m; osum[t] = s; oidx[t] = am; oconf[t] = 1.0f / s;
 }
