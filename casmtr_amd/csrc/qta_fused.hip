@@ -526,6 +526,73 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg,
         ps[e] = ps[e] / s;
         if (e * 64 + lane < Spad) row[e * 64 + lane] = ps[e];  // zero in the [S,Spad) padding
     }
+    // ---- top-k, fast path.  (logit desc, position asc) is a total order, so the answer is the sorted prefix of ANY superset of
+    // the k best.  theta := the k-th largest of the 64 per-lane maxima (a 64-lane bitonic sort of keys): at least k elements
+    // are >= theta, and for rows that are not pathologically concentrated in a few lanes at most 64 are.  Those are compacted
+    // in position order to one per lane through wave-private LDS, sorted across the wave (bitonic, 21 compare-exchange
+    // steps on (key, position)) and the first k lanes store the list.  Probabilities are recomputed from the key with the
+    // formula that produced ps[] above, so they are bit-identical.  Anything else (more than 64 survivors, k > 64) takes
+    // the iterative wave-argmax loop below, which costs ~50 instructions per extracted element.
+    if (topk <= 64) {
+        __shared__ unsigned cbuf[4][2][64];
+        unsigned cur = 0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) cur = max(cur, key[e]);
+        unsigned srt = cur;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned o = (unsigned)__shfl_xor((int)srt, j);
+                const bool keep_max = ((lane & k) == 0) == ((lane & j) == 0);   // descending overall
+                srt = keep_max ? max(srt, o) : min(srt, o);
+            }
+        const unsigned theta = (unsigned)__builtin_amdgcn_readlane((int)srt, topk - 1);
+        int cnt = 0;
+        if (theta != 0u) {
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) cnt += __popcll(__ballot(key[e] >= theta));
+        }
+        if (theta != 0u && cnt <= 64) {   // wave-uniform
+            unsigned* ck = cbuf[wave][0];
+            unsigned* cp = cbuf[wave][1];
+            int base = 0;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const bool f = key[e] >= theta;
+                const unsigned long long bal = __ballot(f);
+                if (f) {
+                    const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    ck[slot] = key[e];
+                    cp[slot] = (unsigned)(e * 64 + lane);
+                }
+                base += __popcll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned sk = lane < cnt ? ck[lane] : 0u;
+            unsigned sp = lane < cnt ? cp[lane] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const unsigned ok = (unsigned)__shfl_xor((int)sk, j);
+                    const unsigned op = (unsigned)__shfl_xor((int)sp, j);
+                    const bool other_first = ok > sk || (ok == sk && op < sp);   // does the partner precede me in the order?
+                    const bool want_first = ((lane & k) == 0) == ((lane & j) == 0);
+                    const bool take = want_first == other_first;
+                    sk = take ? ok : sk;
+                    sp = take ? op : sp;
+                }
+            if (lane < topk) {
+                const size_t o = (((size_t)b * L + l) * topk + lane) * H + h;
+                topk_idx[o] = sp;
+                topk_score[o] = expf(ord2f(sk) - m) / s;
+            }
+            return;
+        }
+    }
     for (int t = 0; t < topk; ++t) {
         unsigned cur = 0;
 #pragma unroll
