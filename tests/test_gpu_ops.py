@@ -306,3 +306,28 @@ def test_empty_batch_and_limits(ops):
                            (4, 4), (40, 40), 2, 2)
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):   # window list longer than 128
         ops.window_match(z(1, 16, 64), z(1, 400, 64), torch.zeros((1, 16, 144), device=DEV, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid"])
+def test_coarse_topk_paths(ops, kind):
+    """coarse-level top-k: the bitonic fast path (<= 64 survivors of the lane-maxima threshold) and the iterative fallback
+    (ties / concentrated rows) must both return the oracle's list, ordered (logit desc, position asc)"""
+    r = np.random.default_rng({"random": 1, "all_equal": 2, "one_lane_heavy": 3, "many_ties": 4, "few_valid": 5}[kind])
+    B, H, L, S, topk = 1, 2, 40, 676, 32
+    if kind == "few_valid":
+        S, topk = 48, 8          # fewer keys than lanes: theta == 0 -> fallback
+    q = r.standard_normal((B, L, H, 32)).astype(np.float32)
+    k = r.standard_normal((B, S, H, 32)).astype(np.float32)
+    v = r.standard_normal((B, S, H, 32)).astype(np.float32)
+    if kind == "all_equal":
+        k[:] = k[:, :1]                      # every key identical -> every logit of a row identical
+    elif kind == "one_lane_heavy":
+        k[:, 5::64] = 3.0 * q[:, :1].mean(axis=1, keepdims=True) + k[:, 5::64]   # positions 5, 69, 133, ... share lane 5
+        q[:] = q[:, :1]                      # same query everywhere so that the boost lines up
+    elif kind == "many_ties":
+        k[:, ::2] = k[:, 1::2]               # every logit appears twice
+    C = H * 32
+    o = oracle.qta_coarse_level(q, k, v, topk)
+    out = ops.qta_coarse_level(T(q.reshape(B, L, C)), T(k.reshape(B, S, C)), T(v.reshape(B, S, C)), H, topk, w_level=1.0)
+    assert np.array_equal(N(out["topk_idx"]), o[2]), kind
+    assert_close(N(out["topk_score"]), o[1], SOFTMAX_TOL, "topk_score")
