@@ -35,6 +35,8 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "casmtr_dual_softmax_ws_bytes": (_SZ, [_I] * 3),
     "casmtr_window_match_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P] + [_I] * 7 + [_P]),
+    "casmtr_window_match_pos_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P] + [_I] * 7 + [_P]),
+    "casmtr_window_expand_idx": (_I, [_P, _P] + [_I] * 7 + [_P]),
     "casmtr_nms_select_fwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _I, _I, _F, _I, _P, _I, _P,
                                    _P, _P, _P, _P, _P] + [_I] * 5 + [_P]),
     "casmtr_nms_select_ws_bytes": (_SZ, [_I] * 3),

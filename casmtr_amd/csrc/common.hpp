@@ -120,6 +120,28 @@ __device__ __forceinline__ cfloat_p as_const(const float* p) {
     return (cfloat_p)(unsigned long long)p;
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B = 1 KiB per wave-instruction straight from global memory into LDS.
+// Destination: wave-uniform LDS byte address + lane * 16 (lane-linear); the SOURCE address is per lane, so any LDS-side
+// swizzle is applied to the source pointer.  No VGPRs hold the data in flight.  Issued through inline asm: hipcc neither
+// counts these loads in its s_waitcnt bookkeeping nor preserves M0 around the statement (guide section 5.5), so the
+// caller waits with glds_wait<N>() -- N = the number of LATER loads that may still be in flight -- and keeps
+// compiler-generated vector-memory instructions out of the span in which a DMA is outstanding.
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
+    return (unsigned)(unsigned long long)p;   // low 32 bits of a flat pointer into the LDS aperture = the LDS offset
+}
+__device__ __forceinline__ void glds16(const float* base, unsigned byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void glds_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// every LDS read issued so far has returned (before a DMA may overwrite the buffer they read)
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // prof.hip
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);

@@ -79,9 +79,11 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
             off += n
 
 
-def gather_matches(out, pairs_per_rank=None, dst: int = 0):
+def gather_matches(out, pairs_per_rank=None, dst: int = 0, pair_offset=None):
     """out: dict with m_bids [M] int64, mkpts0/mkpts1 [M,2], mconf [M].  Returns on rank `dst` a dict with the
-    concatenated lists (m_bids offset to global pair ids) and n_total; None elsewhere.  Single process: passthrough."""
+    concatenated lists (m_bids offset to global pair ids) and n_total; None elsewhere.  Single process: passthrough.
+    Global pair id = local id + pair_offset (this rank's shard_range lower bound -- correct for uneven shards too);
+    pairs_per_rank is the equal-shard shorthand for pair_offset = rank * pairs_per_rank."""
     mk = torch.cat([out["mkpts0"].float(), out["mkpts1"].float(), out["mconf"].float()[:, None]], dim=1)  # [M,5]
     bids = out["m_bids"]
     if not is_dist():
@@ -89,15 +91,17 @@ def gather_matches(out, pairs_per_rank=None, dst: int = 0):
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = mk.device
     cnt = torch.tensor([mk.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt)
-    counts = [int(c.item()) for c in counts]
+    all_cnt = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_cnt, cnt)
+    counts = all_cnt.tolist()   # ONE device->host read-back for all ranks' counts
     mmax = max(max(counts), 1)
     pad_mk = torch.zeros((mmax, 5), dtype=torch.float32, device=dev)
     pad_b = torch.zeros((mmax,), dtype=torch.int64, device=dev)
     pad_mk[: mk.shape[0]] = mk
-    if pairs_per_rank is not None:
-        bids = bids + rank * pairs_per_rank
+    if pair_offset is None and pairs_per_rank is not None:
+        pair_offset = rank * pairs_per_rank
+    if pair_offset:
+        bids = bids + int(pair_offset)
     pad_b[: bids.shape[0]] = bids
     if rank == dst:
         g_mk = [torch.empty_like(pad_mk) for _ in range(world)]

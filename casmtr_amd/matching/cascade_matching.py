@@ -16,7 +16,7 @@ INF = 1e9
 
 
 class CascadeMatching(nn.Module):
-    def __init__(self, config, cas_config, stage=None, div_mode="gpu"):
+    def __init__(self, config, cas_config, stage=None, div_mode="gpu", defer_sync=False, materialize_idx=True):
         super().__init__()
         self.config = config
         self.cas_config = cas_config
@@ -42,16 +42,28 @@ class CascadeMatching(nn.Module):
         self.temperature = config["dsmax_temperature"]
         assert div_mode in ("gpu", "cpu")
         self.recip = div_mode == "gpu"
+        # defer_sync=True: forward() does not read the match count back (no host sync); the match lists stay capacity-sized
+        # until finalize(data, level) is called.  materialize_idx=False: when the window lists arrive as ops.WindowIndex,
+        # data['stage_*']['idx_c01'/'idx_c10'] keep that implicit form (call .materialize() for the int64 tensor).
+        self.defer_sync = defer_sync
+        self.materialize_idx = materialize_idx
 
     def forward(self, feat_c0, feat_c1, idx_c01, idx_c10, data, mask_c0=None, mask_c1=None, heatmap_c0=None, level="4c",
                 pre_level="8c"):
+        """idx_c01 / idx_c10: int64 [B,N,K] as in the reference, or ops.WindowIndex (topk_pos + grid sizes)."""
         if self.training:
-            raise NotImplementedError("CascadeMatching training branch is outside the MI355X hot path")
+            raise NotImplementedError(
+                "CascadeMatching training branch (GT window labels, cascade_matching.py:264-314) is outside the MI355X hot path: "
+                "for training keep the reference's own matcher with casmtr_amd.compat.install(matching=False)")
         hw0, hw1 = tuple(int(x) for x in data[f"hw0_{level}"]), tuple(int(x) for x in data[f"hw1_{level}"])
         f0, f1 = feat_c0.contiguous().float(), feat_c1.contiguous().float()
-        idx_c01, idx_c10 = idx_c01.contiguous(), idx_c10.contiguous()
+        implicit = isinstance(idx_c01, ops.WindowIndex)
+        if not implicit:
+            idx_c01, idx_c10 = idx_c01.contiguous(), idx_c10.contiguous()
         d01 = ops.window_match(f0, f1, idx_c01, self.temperature, mask_c0, mask_c1, recip=self.recip, want_conf=True, hw=hw0)
         d10 = ops.window_match(f1, f0, idx_c10, self.temperature, mask_c1, mask_c0, recip=self.recip, want_conf=False, hw=hw1)
+        if implicit and self.materialize_idx:
+            idx_c01, idx_c10 = idx_c01.materialize(), idx_c10.materialize()
         data[f"stage_{level}"] = {
             "conf_matrix": d01["conf_matrix"], "detector_matrix01": None,
             "next_conf_c01_topk": None, "next_idx_c01_topk": None, "next_conf_c10_topk": None, "next_idx_c10_topk": None,
@@ -65,6 +77,30 @@ class CascadeMatching(nn.Module):
         data[f"stage_{level}"].update(**match_result)
         if "m_bids" in match_result:
             data["m_bids"] = match_result["m_bids"]
+
+    @classmethod
+    def finalize(cls, data, level):
+        """Read the match count back (the host sync of `mask.sum() == 0` / torch.where, cascade_matching.py:254-258) and fill
+        the list keys.  No-op unless forward ran with defer_sync=True."""
+        st = data[f"stage_{level}"]
+        pend = st.pop("_pending", None)
+        if pend is None:
+            return
+        sel, hw0, hw1 = pend
+        st.update(**cls._match_dict(sel, int(sel["n"].item()), hw0, hw1, data, level))
+        data["m_bids"] = st["m_bids"]
+
+    @staticmethod
+    def _match_dict(sel, n, hw0, hw1, data, level):
+        b_ids, i_ids, j_ids, mconf = (sel[k][:n] for k in ("b_ids", "i_ids", "j_ids", "mconf"))
+        w0, w1 = hw0[1], hw1[1]
+        scale = data["hw0_i"][0] / data[f"hw0_{level}"][0]
+        scale0 = scale * data["scale0"][b_ids] if "scale0" in data else scale
+        scale1 = scale * data["scale1"][b_ids] if "scale1" in data else scale
+        mkpts0_c = torch.stack([i_ids % w0, torch.div(i_ids, w0, rounding_mode="trunc")], dim=1) * scale0
+        mkpts1_c = torch.stack([j_ids % w1, torch.div(j_ids, w1, rounding_mode="trunc")], dim=1) * scale1
+        return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "m_bids": b_ids, "mkpts0_c": mkpts0_c,
+                "mkpts1_c": mkpts1_c, "mconf": mconf}
 
     @torch.no_grad()
     def get_coarse_match(self, conf_matrix01, idx_c01, next_conf_c01, next_idx_c01, next_idx_c10, data, level, pre_level):
@@ -81,13 +117,7 @@ class CascadeMatching(nn.Module):
         sel = ops.nms_select(next_conf_c01, next_idx_c01, next_idx_c10, hw0, hw1, nms_window=self.post_process.nms_window,
                              test_thr=float(self.test_thr), pre=pre, border_rm=int(self.border_rm), valid_hw=valid,
                              double_check=bool(self.double_check))
-        n = int(sel["n"].item())  # host sync, as `mask.sum() == 0` / torch.where in the reference (:254-258)
-        b_ids, i_ids, j_ids, mconf = (sel[k][:n] for k in ("b_ids", "i_ids", "j_ids", "mconf"))
-        w0, w1 = hw0[1], hw1[1]
-        scale = data["hw0_i"][0] / data[f"hw0_{level}"][0]
-        scale0 = scale * data["scale0"][b_ids] if "scale0" in data else scale
-        scale1 = scale * data["scale1"][b_ids] if "scale1" in data else scale
-        mkpts0_c = torch.stack([i_ids % w0, torch.div(i_ids, w0, rounding_mode="trunc")], dim=1) * scale0
-        mkpts1_c = torch.stack([j_ids % w1, torch.div(j_ids, w1, rounding_mode="trunc")], dim=1) * scale1
-        return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "m_bids": b_ids, "mkpts0_c": mkpts0_c,
-                "mkpts1_c": mkpts1_c, "mconf": mconf}
+        if self.defer_sync:
+            return {"_pending": (sel, hw0, hw1)}
+        # host sync, as `mask.sum() == 0` / torch.where in the reference (:254-258)
+        return self._match_dict(sel, int(sel["n"].item()), hw0, hw1, data, level)

@@ -293,17 +293,21 @@ class CascadeQTAttB(nn.Module):
         message = _raster_order(message, h0, w0).reshape(bs, h0 * w0, c)
         return message, _raster_order(idx5[..., 0], h0, w0)
 
-    def forward(self, query, key, value, topk_pos, rel_pos):
+    def forward(self, query, key, value, topk_pos, rel_pos, want_idx=True):
         """query/key/value [N,C,H,W]; topk_pos [N,(H/2)(W/2),KW,2] (row,col) -> message [N,HW,C], upsampled_idx
-        [N,HW,4*KW]  (modules/quadtree_attention.py:400-452)."""
+        [N,HW,4*KW]  (modules/quadtree_attention.py:400-452).
+        want_idx=False (no reference counterpart): the second return value is None.  Every cross layer of a
+        CascadeFeatureTransformer returns the SAME index tensor (it depends on topk_pos only, transformer.py:549) and only the
+        last one is used, so callers that hold topk_pos (ops.WindowIndex) can skip the 8*N*4KW-byte write entirely."""
         if _needs_autograd(query, key, value, rel_pos):
             return self._forward_composed(query, key, value, topk_pos, rel_pos)
         q, k, v = ops.nchw_to_tokens_multi([t.float() for t in (query, key, value)])
-        return self.forward_tokens(q, k, v, tuple(query.shape[2:]), tuple(key.shape[2:]), topk_pos, rel_pos)
+        return self.forward_tokens(q, k, v, tuple(query.shape[2:]), tuple(key.shape[2:]), topk_pos, rel_pos, want_idx)
 
-    def forward_tokens(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None):
+    def forward_tokens(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None, want_idx=True):
         """Token-major entry point: q [N,h0*w0,C], k/v [N,h1*w1,C].  Inference only."""
         if _needs_autograd(q, k, v, rel_pos):
             raise RuntimeError("CascadeQTAttB.forward_tokens is the inference path: use forward() for autograd")
         rp = None if rel_pos is None else rel_pos.contiguous().float()
-        return ops.cascade_attn(q, k, v, topk_pos.contiguous(), tuple(hw_q), tuple(hw_k), self.nhead, self.dilated, rp)
+        return ops.cascade_attn(q, k, v, topk_pos.contiguous(), tuple(hw_q), tuple(hw_k), self.nhead, self.dilated, rp,
+                                want_idx=want_idx)

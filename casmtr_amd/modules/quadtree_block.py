@@ -136,9 +136,9 @@ class CascadeQuadtreeAttention(nn.Module):
         self.scale = scale
         self.apply(_init_weights)
 
-    def forward(self, x, target, H, W, H1=None, W1=None, idx=None, rel_pos=None):
+    def forward(self, x, target, H, W, H1=None, W1=None, idx=None, rel_pos=None, want_idx=True):
         """x [B,H*W,C], target [B,H1*W1,C], idx [B,(H/2)(W/2),KW,2] -> (x' [B,H*W,C], upsampled_idx [B,H*W,4KW])
-        (src/model/modules/quadtree_attention.py:152-176)."""
+        (src/model/modules/quadtree_attention.py:152-176).  want_idx=False: see CascadeQTAttB.forward."""
         H1 = H if H1 is None else H1
         W1 = W if W1 is None else W1
         B, N, C = x.shape
@@ -146,7 +146,7 @@ class CascadeQuadtreeAttention(nn.Module):
             rel_pos = rel_pos.to(torch.float32)
         if x.is_cuda and not _needs_autograd(x, target, rel_pos, *self.parameters()):
             q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
-            msg, upsampled_idx = self.cross_attn.forward_tokens(q, k, v, (H, W), (H1, W1), idx, rel_pos)
+            msg, upsampled_idx = self.cross_attn.forward_tokens(q, k, v, (H, W), (H1, W1), idx, rel_pos, want_idx)
             out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
                              None if self.proj.bias is None else self.proj.bias.detach().float())
             return self.proj_drop(out), upsampled_idx

@@ -290,8 +290,40 @@ def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=No
                 next_conf_c10=nc10, b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n)
 
 
+class WindowIndex:
+    """The window lists of a cascade stage in their implicit form: `topk_pos` [B,(h0/2)*(w0/2),KW,2] (row, col) on the
+    (h1/2)x(w1/2) grid, as CascadeFeatureTransformer.get_window_warp_idx produces it (transformer.py:416-440).  Equivalent to
+    CascadeQTAttB's `upsampled_idx` [B,h0*w0,4*KW] (modules/quadtree_attention.py:419-450), which is 16x larger and identical
+    for the 4 children of a quad; window_match() consumes this form directly, materialize() builds the explicit tensor."""
+
+    def __init__(self, topk_pos, hw0, hw1, dilated=1):
+        _chk(topk_pos, "topk_pos", torch.int64)
+        self.topk_pos, self.hw0, self.hw1, self.dilated = topk_pos, tuple(int(x) for x in hw0), tuple(int(x) for x in hw1), int(dilated)
+        B, Lq, KW, two = topk_pos.shape
+        if two != 2 or Lq * 4 != self.hw0[0] * self.hw0[1]:
+            raise RuntimeError("WindowIndex: topk_pos must be [B,(h0/2)*(w0/2),KW,2]")
+        self._full = None
+
+    @property
+    def shape(self):
+        B, Lq, KW, _ = self.topk_pos.shape
+        return (B, Lq * 4, 4 * KW)
+
+    def materialize(self):
+        if self._full is None:
+            B, N, K = self.shape
+            out = torch.empty((B, N, K), device=self.topk_pos.device, dtype=torch.int64)
+            with torch.cuda.device(out.device):
+                _lib.check(_lib.lib().casmtr_window_expand_idx(_ptr(self.topk_pos), _ptr(out), B, self.hw0[0], self.hw0[1],
+                                                               self.hw1[0], self.hw1[1], K // 4, self.dilated, _stream()),
+                           "window_expand_idx")
+            self._full = out
+        return self._full
+
+
 def window_match(feat_q, feat_k, idx, temperature=1.0, mask_q=None, mask_k=None, recip=True, want_conf=True, hw=None):
-    _chk(feat_q, "feat_q"), _chk(feat_k, "feat_k"), _chk(idx, "idx", torch.int64)
+    """idx: int64 [B,N,K] (the reference's upsampled_idx) or a WindowIndex (implicit form, no index tensor in HBM)."""
+    _chk(feat_q, "feat_q"), _chk(feat_k, "feat_k")
     mask_q, mask_k = _u8(mask_q), _u8(mask_k)
     B, N, Cc = feat_q.shape
     M, K = feat_k.shape[1], idx.shape[2]
@@ -299,6 +331,17 @@ def window_match(feat_q, feat_k, idx, temperature=1.0, mask_q=None, mask_k=None,
     conf = torch.empty((B, N, K), device=dev, dtype=torch.float32) if want_conf else None
     nc = torch.empty((B, N), device=dev, dtype=torch.float32)
     ni = torch.empty((B, N), device=dev, dtype=torch.int64)
+    if isinstance(idx, WindowIndex):
+        if tuple(idx.shape[:2]) != (B, N) or idx.hw1[0] * idx.hw1[1] != M:
+            raise RuntimeError("window_match: WindowIndex does not match the feature shapes")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().casmtr_window_match_pos_fwd(_ptr(feat_q), _ptr(feat_k), _ptr(idx.topk_pos), _ptr(mask_q),
+                                                               _ptr(mask_k), float(temperature), int(bool(recip)), idx.dilated,
+                                                               _ptr(conf), _ptr(nc), _ptr(ni), B, idx.hw0[0], idx.hw0[1],
+                                                               idx.hw1[0], idx.hw1[1], K // 4, Cc, _stream()),
+                       "window_match_pos_fwd")
+        return dict(conf_matrix=conf, next_conf=nc, next_idx=ni)
+    _chk(idx, "idx", torch.int64)
     h, w = hw if hw is not None else (0, 0)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().casmtr_window_match_fwd(_ptr(feat_q), _ptr(feat_k), _ptr(idx), _ptr(mask_q), _ptr(mask_k),

@@ -123,6 +123,19 @@ int casmtr_window_match_fwd(const float* feat_q, const float* feat_k, const int6
                             int64_t* next_idx, int B, int N, int M, int K, int C, int h, int w,
                             casmtr_stream_t stream);
 
+/* The same on IMPLICIT windows: instead of idx [B,N,4*KW] the kernel takes the topk_pos [B,(h0/2)*(w0/2),KW,2] (row,col on the
+ * (h1/2)x(w1/2) grid) that CascadeQTAttB expands into it (cuda_imp/.../modules/quadtree_attention.py:419-450: 4 children per
+ * position, parent-major, offsets (0,0),(0,d),(d,0),(d,d), clamped to [0,h1*w1-1]; every child of a query quad gets the same
+ * list).  Results are identical to casmtr_window_match_fwd on the expanded tensor; 4*KW <= 128, h0 and w0 even.            */
+int casmtr_window_match_pos_fwd(const float* feat_q, const float* feat_k, const int64_t* topk_pos, const uint8_t* mask_q,
+                                const uint8_t* mask_k, float temperature, int recip, int dilated, float* conf,
+                                float* next_conf, int64_t* next_idx, int B, int h0, int w0, int h1, int w1, int KW, int C,
+                                casmtr_stream_t stream);
+/* ... and the expansion itself, for callers that want the explicit tensor (data['stage_4c']['idx_c01'], training
+ * supervision): up_idx [B,h0*w0,4*KW] int64 == CascadeQTAttB's second return value.                                        */
+int casmtr_window_expand_idx(const int64_t* topk_pos, int64_t* up_idx, int B, int h0, int w0, int h1, int w1, int KW,
+                             int dilated, casmtr_stream_t stream);
+
 /* CascadeMatching.get_coarse_match, inference branch (cascade_matching.py:170-261,317-331) with
  * PostProcess.apply for method None / 'maxpool_nms' (post_processing.py:41-44,111-121) and
  * mask_window_border[_with_padding] (cascade_functions.py:120-172).

@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 
 torch.set_num_threads(8)
-from golden_inputs import CASES, make_inputs, checksum  # noqa: E402  (tests/golden_inputs.py)
+from golden_inputs import CASES, GRAD_CASES, make_inputs, make_grad_inputs, checksum  # noqa: E402  (tests/golden_inputs.py)
 
 
 # ------------------------------------------------------------------------------------------------ stubs
@@ -80,9 +80,40 @@ def _fast_score_forward(query, key, index):
     return [(query.unsqueeze(2) * g).sum(-1)]
 
 
+# Backward entry points of the stub extensions: torch autograd through the authors' python equivalents above, in the
+# calling convention of score_computation.cpp:22-33 / value_aggregation.cpp:33-60 / score_cuda score_computation.cpp:17-27
+# (the reference's autograd.Functions call these from their backward()).
+def _vjp(fn, inputs, grad):
+    leaves = [t.detach().clone().requires_grad_(True) for t in inputs]
+    with torch.enable_grad():
+        out = fn(*leaves)
+    return list(torch.autograd.grad(out, leaves, grad))
+
+
+def _score_backward(grad, query, key, index):
+    return _vjp(lambda q, k: _score_forward(q, k, index)[0], (query, key), grad)
+
+
+def _value_aggregation_backward(grad_out, score, value, index, grad_score, grad_value):
+    def f(s, v):   # _value_aggregation_forward without the copy into the caller's buffer
+        return torch.sum(s.unsqueeze(-1) * _gather_rows(v, index), dim=2)
+
+    # the reference hands grad_output over as [b, n, f, h, d] (functions/quadtree_attention.py:47): same memory as [b, n*f, h, d]
+    gs, gv = _vjp(f, (score, value), grad_out.reshape(score.shape[0], score.shape[1], *grad_out.shape[-2:]))
+    grad_score.add_(gs)
+    grad_value.add_(gv)
+
+
+def _fast_score_backward(grad, query, key, index):
+    return _vjp(lambda q, k: _fast_score_forward(q, k, index)[0], (query, key), grad)
+
+
 sc_ext.score_forward = _score_forward
+sc_ext.score_backward = _score_backward
 va_ext.value_aggregation_forward = _value_aggregation_forward
+va_ext.value_aggregation_backward = _value_aggregation_backward
 fs_ext.score_forward = _fast_score_forward
+fs_ext.score_backward = _fast_score_backward
 
 from cuda_imp.QuadTreeAttention.QuadtreeAttention.modules import quadtree_attention as qta  # noqa: E402
 from cuda_imp.QuadTreeAttention.QuadtreeAttention.functions import quadtree_attention as qta_fn  # noqa: E402
@@ -307,8 +338,54 @@ def gen_cascade_matching():
         save("cascade_matching_" + name, checksum=checksum(inp), idx_c01=ups[0], idx_c10=ups[1], **keep)
 
 
+def gen_grads():
+    """a12 / f2: gradients of the three primitive ops and of QTAttB / CascadeQTAttB, produced by the reference's own
+    autograd.Functions (functions/quadtree_attention.py:7-57, cascade_functions.py:8-22) and modules running backward()."""
+    for name in GRAD_CASES["ops"]:
+        inp, gi = make_inputs("ops", name), make_grad_inputs("ops", name)
+        q, key = T(inp["q"]).requires_grad_(True), T(inp["key"]).requires_grad_(True)
+        qta_fn.score_computation_op(q, key, T(inp["idx"])).backward(T(gi["g_score"]))
+        sc, val = T(gi["agg_score"]).requires_grad_(True), T(inp["value"]).requires_grad_(True)
+        idx5 = T(inp["idx"]).unsqueeze(2).repeat(1, 1, 4, 1, 1)
+        qta_fn.value_aggregation_op(sc, val, idx5).backward(T(gi["g_msg"]))
+        wq, wk = T(inp["wq"]).requires_grad_(True), T(inp["wkey"]).requires_grad_(True)
+        cf.ScoreComputation.apply(wq, wk, T(inp["widx"])).backward(T(gi["g_window"]))
+        save("grads_ops_" + name, checksum=checksum(inp), gchecksum=checksum(gi), score_dq=q.grad, score_dkey=key.grad,
+             agg_dscore=sc.grad, agg_dvalue=val.grad, window_dq=wq.grad, window_dkey=wk.grad)
+    for name in GRAD_CASES["qtattb"]:
+        cfg = CASES["qtattb"][name]
+        inp, gi = make_inputs("qtattb", name), make_grad_inputs("qtattb", name)
+        out = {"checksum": checksum(inp), "gchecksum": checksum(gi)}
+        for tag, cls in (("cuda", qta.QTAttB), ("smart", smart.QTAttB)):
+            m = cls(cfg["nhead"], cfg["D"], scale=3, topks=cfg["topks"])
+            with torch.no_grad():
+                m.weight.copy_(T(inp["weight"]))
+            qs, ks, vs = ([T(x).requires_grad_(True) for x in inp[n]] for n in ("queries", "keys", "values"))
+            m(qs, ks, vs).backward(T(gi["g_final"]))
+            grads = {f"d{n}{lv}": t.grad for n, ts in (("q", qs), ("k", ks), ("v", vs)) for lv, t in enumerate(ts)}
+            grads["dweight"] = m.weight.grad
+            if tag == "cuda":
+                out.update(grads)
+            else:   # the pure-torch module must produce the same gradients as the CUDA-path module over the stub ops
+                out["smart_vs_cuda_maxabs"] = np.array([max((grads[k] - out[k]).abs().max().item() for k in grads)])
+        save("grads_qtattb_" + name, **out)
+    for name in GRAD_CASES["cascade_attn"]:
+        cfg = CASES["cascade_attn"][name]
+        inp, gi = make_inputs("cascade_attn", name), make_grad_inputs("cascade_attn", name)
+        hc, wc = cfg["coarse_hw"]
+        ns = types.SimpleNamespace(window=window_offsets(cfg["ws"]), full_window=None)
+        topk_pos, _ = CascadeFeatureTransformer.get_window_warp_idx(ns, T(inp["coarse_idx"]), inp["q"].shape[0], hc, wc)
+        m = qta.CascadeQTAttB(cfg["nhead"], cfg["D"], dilated=1)
+        q, k, v = (T(inp[n]).requires_grad_(True) for n in "qkv")
+        rel = T(inp["rel_pos"]).requires_grad_(True) if cfg.get("rel_pos") else None
+        msg, _ = m(q, k, v, topk_pos, rel)
+        msg.backward(T(gi["g_message"]))
+        extra = {"drel_pos": rel.grad} if rel is not None else {}
+        save("grads_cascade_attn_" + name, checksum=checksum(inp), gchecksum=checksum(gi), dq=q.grad, dk=k.grad, dv=v.grad, **extra)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "qtattb", "qtatt_variants", "cascade_attn", "coarse_matching", "cascade_matching",
-                              "quadtree_block"]
+                              "quadtree_block", "grads"]
     for w in which:
         globals()["gen_" + w]()

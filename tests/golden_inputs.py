@@ -185,6 +185,27 @@ def make_inputs(group, name):
     raise KeyError(group)
 
 
+def make_grad_inputs(group, name):
+    """Seeded upstream gradients (and the extra forward inputs the backward fixtures need), a12 / f2.
+    Separate generator (seed + 1000) so that the forward fixtures' inputs and checksums stay what they were."""
+    cfg = CASES[group][name]
+    r = _rng(cfg["seed"] + 1000)
+    if group == "ops":
+        B, N1, N2, K, H, D = (cfg[k] for k in ("B", "N1", "N2", "K", "H", "D"))
+        return dict(g_score=_randn(r, B, N1, 4, K, H), agg_score=r.random((B, N1, 4, K, H), dtype=np.float32),
+                    g_msg=_randn(r, B, N1, 4, H, D), g_window=_randn(r, B, N1 * 4, cfg["WK"]))
+    if group == "qtattb":
+        B, (h, w), H, D = cfg["B"], cfg["hw"], cfg["nhead"], cfg["D"]
+        return dict(g_final=_randn(r, B, h * w, H, D))
+    if group == "cascade_attn":
+        B, (hc, wc), H, D = cfg["B"], cfg["coarse_hw"], cfg["nhead"], cfg["D"]
+        return dict(g_message=_randn(r, B, 4 * hc * wc, H * D))
+    raise KeyError(group)
+
+
+GRAD_CASES = {"ops": list(CASES["ops"]), "qtattb": ["g16x16", "g32x24_cross"], "cascade_attn": ["c16_f32", "c12x20_relpos"]}
+
+
 def checksum(inp):
     """crc32 over every input array, stored in the fixture to detect RNG drift."""
     c = 0

@@ -19,26 +19,51 @@ def assert_close(a, b, atol, what=""):
     return err
 
 
-def topk_index_audit(idx_a, idx_b, logits_of_a=None, logits_of_b=None, ulp_tol=8):
-    """Bit-match two top-k index tensors [..., k, H] (sorted by score).  Returns (n_rows, n_mismatch_rows).
-
-    A mismatching series is accepted only as a NEAR TIE: the two series must select the same SET of indices except
-    for elements whose logits differ by <= ulp_tol ulps, or be a pure reordering of near-equal logits.  When logits
-    are not supplied, only set-equality up to reordering is tolerated and counted.
-    """
-    a = np.asarray(idx_a).astype(np.int64)
-    b = np.asarray(idx_b).astype(np.int64)
-    assert a.shape == b.shape
-    neq = (a != b).any(axis=-2)  # [..., H]
-    return int(neq.size), int(neq.sum())
+def near_tie(sa, sb, rel=4e-6, absolute=1e-6):
+    """two fp32-chain scores that an exact (float64) evaluation cannot tell apart beyond accumulation-order rounding"""
+    return abs(sa - sb) <= absolute + rel * max(abs(sa), abs(sb))
 
 
-def ulp_diff(x, y):
-    x = np.asarray(x, np.float32).view(np.int32).astype(np.int64)
-    y = np.asarray(y, np.float32).view(np.int32).astype(np.int64)
-    x = np.where(x < 0, -(x & 0x7FFFFFFF), x)
-    y = np.where(y < 0, -(y & 0x7FFFFFFF), y)
-    return np.abs(x - y)
+def audit_index_mismatches(got, want, score_fn, what):
+    """Index tensors (argmax / gathered absolute indices) must be EQUAL; an element may differ only as a NEAR TIE:
+    `score_fn(position_tuple, index) -> float` evaluates, in float64, the quantity the index was selected on, and the two
+    candidates' scores must agree within fp32 rounding.  Returns the number of (audited) mismatches."""
+    got, want = np.asarray(got).astype(np.int64), np.asarray(want).astype(np.int64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    bad = np.argwhere(got != want)
+    for pos in bad:
+        pos = tuple(int(x) for x in pos)
+        sg, sw = float(score_fn(pos, int(got[pos]))), float(score_fn(pos, int(want[pos])))
+        assert near_tie(sg, sw), f"{what}: index differs at {pos}: {got[pos]} (score {sg!r}) vs {want[pos]} ({sw!r}) -- not a near tie"
+    return len(bad)
+
+
+def audit_topk_mismatches(got, want, logit_fn, what):
+    """Top-k index tensors [B, L, k, H] (sorted by score, descending) must be EQUAL; a (b, l, h) series may differ only by
+    near ties: `logit_fn(b, l, h, idx_vector) -> float64 logits` of the selected keys; rank by rank the two lists must carry
+    (numerically) the same logit, i.e. they differ by swaps of near-equal scores or at the k-th boundary by a near-equal
+    substitute.  Returns the number of (audited) mismatching series."""
+    got, want = np.asarray(got).astype(np.int64), np.asarray(want).astype(np.int64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    bad = np.argwhere((got != want).any(axis=2))
+    for b, l, h in bad:
+        lg, lw = logit_fn(b, l, h, got[b, l, :, h]), logit_fn(b, l, h, want[b, l, :, h])
+        for t, (x, y) in enumerate(zip(lg, lw)):
+            assert near_tie(float(x), float(y)), f"{what}: series (b={b}, l={l}, h={h}) differs beyond a near tie at rank {t}: {x!r} vs {y!r}"
+    return len(bad)
+
+
+def dot_score_fn(fa, fb, mask_a=None, mask_b=None):
+    """score_fn for audit_index_mismatches on similarity argmaxes: position (b, n) with candidate index j -> <fa[b,n], fb[b,j]>
+    in float64 (-1e9 where either side is masked, as the reference fills).  Scale factors are monotone and irrelevant."""
+    fa, fb = np.asarray(fa, np.float64), np.asarray(fb, np.float64)
+
+    def fn(pos, j):
+        b, n = pos
+        if mask_a is not None and not (mask_a[b, n] and mask_b[b, j]):
+            return -1e9
+        return float(fa[b, n] @ fb[b, j])
+    return fn
 
 
 def match_set(b, i, j):

@@ -34,10 +34,15 @@ def _worker(rank, world, port, q):
     out = {"m_bids": torch.arange(M) % 2, "mkpts0": torch.full((M, 2), float(rank)), "mkpts1": torch.full((M, 2), 7.0),
            "mconf": torch.linspace(0, 1, M) if M else torch.zeros(0)}
     res = cdist.gather_matches(out, pairs_per_rank=2)
+    # uneven shards (5 pairs over 2 ranks = 3 + 2): global pair ids come from the shard's lower bound, not rank * per_rank
+    out2 = {"m_bids": torch.arange(hi - lo), "mkpts0": torch.zeros((hi - lo, 2)), "mkpts1": torch.zeros((hi - lo, 2)),
+            "mconf": torch.ones(hi - lo)}
+    res2 = cdist.gather_matches(out2, pair_offset=lo)
     t = cdist.max_over_ranks(float(rank))
     cdist.barrier()
     if rank == 0:
-        q.put(dict(range=(lo, hi), n=res["n_total"], counts=res["counts"], bids=res["m_bids"].tolist(), shape=tuple(res["mk"].shape), tmax=t))
+        q.put(dict(range=(lo, hi), n=res["n_total"], counts=res["counts"], bids=res["m_bids"].tolist(), shape=tuple(res["mk"].shape), tmax=t,
+                   uneven_bids=res2["m_bids"].tolist()))
     else:
         assert res is None
         q.put(dict(range=(lo, hi)))
@@ -59,6 +64,7 @@ def test_world2_gloo():
     assert ranges == [(0, 3), (3, 5)]
     r0 = next(o for o in outs if "n" in o)
     assert r0["n"] == 4 and r0["counts"] == [4, 0] and r0["shape"] == (4, 5) and r0["bids"] == [0, 1, 0, 1] and r0["tmax"] == 1.0
+    assert r0["uneven_bids"] == [0, 1, 2, 3, 4], "every pair of an uneven partition keeps its own global id"
 
 
 def test_single_process_passthrough():

@@ -6,7 +6,7 @@ import torch
 
 import oracle
 from golden_inputs import CASES, make_inputs
-from parity_utils import assert_close, load_golden, match_set
+from parity_utils import assert_close, audit_index_mismatches, dot_score_fn, load_golden, match_set
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -82,8 +82,10 @@ def test_coarse_matching_module(name):
     with torch.no_grad():
         cm(T(inp["feat0"]), T(inp["feat1"]), data, mask_c0=m0, mask_c1=m1, level="8c")
     st = data["stage_8c"]
-    assert (N(st["next_idx_c01"]) != g["next_idx_c01"]).mean() <= 1e-3
-    assert (N(st["next_idx_c10"]) != g["next_idx_c10"]).mean() <= 1e-3
+    mk0 = inp["mask0"].reshape(cfg["B"], -1) if cfg.get("masks") else None
+    mk1 = inp["mask1"].reshape(cfg["B"], -1) if cfg.get("masks") else None
+    audit_index_mismatches(N(st["next_idx_c01"]), g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], mk0, mk1), "next_idx_c01")
+    audit_index_mismatches(N(st["next_idx_c10"]), g["next_idx_c10"], dot_score_fn(inp["feat1"], inp["feat0"], mk1, mk0), "next_idx_c10")
     assert_close(N(st["next_conf_c01"]), g["next_conf_c01"], TOL, "next_conf_c01")
     if "conf_matrix" in g:
         assert_close(N(st["conf_matrix"]), g["conf_matrix"], TOL, "conf_matrix")
@@ -120,7 +122,10 @@ def test_cascade_matching_module(name):
     st = data["stage_4c"]
     assert_close(N(st["conf_matrix"]), g["conf_matrix"], TOL, "conf_matrix01")
     assert_close(N(st["next_conf_c01"]), g["next_conf_c01"], TOL, "next_conf_c01")
-    assert (N(st["next_idx_c01"]) != g["next_idx_c01"]).mean() <= 2e-3
+    mq = inp["mask0"].reshape(cfg["B"], -1) if cfg.get("masks") else None
+    mk = inp["mask1"].reshape(cfg["B"], -1) if cfg.get("masks") else None
+    audit_index_mismatches(N(st["next_idx_c01"]), g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], mq, mk), "cascade next_idx_c01")
+    audit_index_mismatches(N(st["next_idx_c10"]), g["next_idx_c10"], dot_score_fn(inp["feat1"], inp["feat0"], mk, mq), "cascade next_idx_c10")
     got, want = match_set(N(st["b_ids"]), N(st["i_ids"]), N(st["j_ids"])), match_set(g["b_ids"], g["i_ids"], g["j_ids"])
     # selection thresholds act on softmax values that differ by ulps between CPU and GPU expf -> borderline only
     assert len(got ^ want) <= max(1, len(want) // 100), (len(got), len(want))
@@ -146,45 +151,84 @@ def test_compat_reference_names_on_gpu():
     assert out.abs().sum() > 0
 
 
-@pytest.mark.parametrize("B", [1])
-def test_full_size_chain_vs_oracle(B):
-    """BASELINE configs[1] shapes (CasMTR-4c, 832x832): every index output of the chain bit-matches the oracle."""
+def _valid_hw(m0, m1):
+    return np.stack([m0.sum(1).max(-1), m0.sum(2).max(-1), m1.sum(1).max(-1), m1.sum(2).max(-1)], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("masked", [False, True], ids=["configs1_unmasked", "configs2_padding_masks"])
+def test_full_size_chain_vs_oracle(masked):
+    """BASELINE configs[1] / configs[2] shapes (CasMTR-4c, 832x832, batch of 8; configs[2]: MegaDepth-style padding masks):
+    every index output of the chain bit-matches the oracle, for the FIRST and the LAST pair of the batch."""
+    from casmtr_amd import ops
     from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
-    cfg = HotPathConfig()
+    B = 8
+    cfg = HotPathConfig(masked=masked, implicit_windows=False)   # explicit int64 windows: data['stage_4c']['idx_c01'] is checked too
     model = HotPath(cfg).to(DEV)
     inp = make_synthetic_inputs(cfg, B, DEV, seed=7)
     with torch.no_grad():
         model.qta.weight.copy_(inp["weight"])
         out = model(inp)
+        out_imp = HotPath(HotPathConfig(masked=masked, implicit_windows=True)).to(DEV)
+        out_imp.qta.weight.copy_(inp["weight"])
+        out_imp = out_imp(inp)
     torch.cuda.synchronize()
     d = out["data"]
-    n = lambda t: N(t[:1])
-    # QTAttB: one cross call at the full 104x104 grid
-    fo, lv = oracle.qtattb_forward([n(x) for x in inp["cq0"]], [n(x) for x in inp["ck1"]], [n(x) for x in inp["cv1"]],
-                                   N(inp["weight"]), cfg.coarse_heads, cfg.coarse_topks)
-    assert_close(N(out["messages"][2][:1]), fo, TOL, "QTAttB cross message (104x104)")
-    # coarse matching
-    o8 = oracle.dual_softmax(n(inp["feat_8c0"]), n(inp["feat_8c1"]), cfg.hw8, cfg.hw8, cfg.coarse_temperature, cfg.coarse_thr,
-                             cfg.coarse_border_rm, recip=True)
-    st8 = d["stage_8c"]
-    assert np.array_equal(N(st8["next_idx_c01"][:1]), o8["next_idx_c01"]), "coarse row argmax (10816 x 10816)"
-    assert np.array_equal(N(st8["next_idx_c10"][:1]), o8["next_idx_c10"]), "coarse column argmax"
-    assert_close(N(st8["next_conf_c01"][:1]), o8["next_conf_c01"], TOL, "coarse next_conf")
-    sel = N(st8["b_ids"]) == 0
-    got = match_set(N(st8["b_ids"])[sel], N(st8["i_ids"])[sel], N(st8["j_ids"])[sel])
-    want = match_set(o8["b_ids"], o8["i_ids"], o8["j_ids"])
-    assert len(got ^ want) <= max(1, len(want) // 1000) and len(want) > 1000
-    # cascade attention + matching
-    tp01 = oracle.window_warp_idx(o8["next_idx_c01"], *cfg.hw8, cfg.window_size)
-    tok = lambda x: np.ascontiguousarray(n(x).transpose(0, 2, 3, 1).reshape(1, -1, cfg.cascade_dim))
-    mo, i01 = oracle.cascade_attn(tok(inp["fq0"]), tok(inp["fk1"]), tok(inp["fv1"]), tp01, cfg.hw4, cfg.hw4, cfg.cascade_heads)
-    st4 = d["stage_4c"]
-    assert np.array_equal(N(st4["idx_c01"][:1]), i01), "upsampled window indices"
-    assert_close(N(out["messages"][12][:1]), mo, TOL, "CascadeQTAttB message (208x208)")
-    m01 = oracle.window_match(n(inp["feat_4c0"]), n(inp["feat_4c1"]), i01, cfg.cascade_temperature, recip=True)
-    assert np.array_equal(N(st4["next_idx_c01"][:1]), m01["next_idx"]), "cascade argmax (43264 x 100)"
-    assert_close(N(st4["conf_matrix"][:1]), m01["conf_matrix"], TOL, "cascade conf_matrix")
-    assert out["mconf"].numel() > 100
+    st8, st4 = d["stage_8c"], d["stage_4c"]
+    # the implicit-window data flow (topk_pos instead of the int64 index tensor) gives the same answers, bit for bit
+    for k in ("next_idx_c01", "next_idx_c10", "next_conf_c01", "conf_matrix", "b_ids", "i_ids", "j_ids", "mconf"):
+        assert torch.equal(out_imp["data"]["stage_4c"][k], st4[k]), f"implicit windows: stage_4c[{k}] differs"
+    assert torch.equal(out_imp["data"]["stage_4c"]["idx_c01"].materialize(), st4["idx_c01"])
+    # QTAttB per-level indices at 26x26 / 52x52 / 104x104 for the whole batch (layer 1 = first cross layer, direction 0 -> 1)
+    toks = ops.nchw_to_tokens_multi([x.contiguous() for lv in (2, 1, 0) for x in (inp["cq0"][1][lv], inp["ck1"][1][lv], inp["cv1"][1][lv])])
+    levels_gpu, prev = [], None
+    for i in range(3):
+        q, k, v = toks[3 * i:3 * i + 3]
+        hw = tuple(inp["cq0"][1][2 - i].shape[2:])
+        o = (ops.qta_coarse_level(q, k, v, cfg.coarse_heads, cfg.coarse_topks[0]) if i == 0 else
+             ops.qta_fine_level(q, k, v, prev, hw, hw, cfg.coarse_heads, cfg.coarse_topks[i]))
+        prev = o["topk_idx"]
+        levels_gpu.append(o)
+    for e in (0, B - 1):
+        n = lambda t: N(t[e:e + 1])
+        fo, lv = oracle.qtattb_forward([n(x) for x in inp["cq0"][1]], [n(x) for x in inp["ck1"][1]], [n(x) for x in inp["cv1"][1]],
+                                       N(inp["weight"]), cfg.coarse_heads, cfg.coarse_topks)
+        for i, side in enumerate((26, 52, 104)):
+            assert np.array_equal(n(levels_gpu[i]["topk_idx"]), lv[i]["topk_idx"]), f"pair {e}: top-k indices at {side}x{side}"
+            assert_close(n(levels_gpu[i]["topk_score"]), lv[i]["topk_score"], TOL, f"pair {e}: top-k scores at {side}x{side}")
+        assert_close(n(out["messages"][2]), fo, TOL, f"pair {e}: QTAttB cross message (104x104)")
+        # coarse matching
+        mk = (lambda lvl, im: n(inp[f"mask_{lvl}{im}"]).reshape(1, -1)) if masked else (lambda lvl, im: None)
+        vh = (lambda lvl: _valid_hw(n(inp[f"mask_{lvl}0"]), n(inp[f"mask_{lvl}1"]))) if masked else (lambda lvl: None)
+        o8 = oracle.dual_softmax(n(inp["feat_8c0"]), n(inp["feat_8c1"]), cfg.hw8, cfg.hw8, cfg.coarse_temperature, cfg.coarse_thr,
+                                 cfg.coarse_border_rm, mask0=mk("8c", 0), mask1=mk("8c", 1), valid_hw=vh("8c"), recip=True)
+        assert np.array_equal(n(st8["next_idx_c01"]), o8["next_idx_c01"]), f"pair {e}: coarse row argmax (10816 x 10816)"
+        assert np.array_equal(n(st8["next_idx_c10"]), o8["next_idx_c10"]), f"pair {e}: coarse column argmax"
+        assert_close(n(st8["next_conf_c01"]), o8["next_conf_c01"], TOL, "coarse next_conf")
+        sel = N(st8["b_ids"]) == e
+        got = match_set(0 * N(st8["i_ids"])[sel], N(st8["i_ids"])[sel], N(st8["j_ids"])[sel])
+        want = match_set(o8["b_ids"], o8["i_ids"], o8["j_ids"])
+        assert len(got ^ want) <= 1 and len(want) > 1000, "coarse match list (only a conf == thr borderline entry may differ)"
+        # cascade attention + matching
+        tp01 = oracle.window_warp_idx(o8["next_idx_c01"], *cfg.hw8, cfg.window_size)
+        tp10 = oracle.window_warp_idx(o8["next_idx_c10"], *cfg.hw8, cfg.window_size)
+        tok = lambda x: np.ascontiguousarray(n(x).transpose(0, 2, 3, 1).reshape(1, -1, cfg.cascade_dim))
+        mo, i01 = oracle.cascade_attn(tok(inp["4cq0"][0]), tok(inp["4ck1"][0]), tok(inp["4cv1"][0]), tp01, cfg.hw4, cfg.hw4, cfg.cascade_heads)
+        _, i10 = oracle.cascade_attn(tok(inp["4cq1"][0]), tok(inp["4ck0"][0]), tok(inp["4cv0"][0]), tp10, cfg.hw4, cfg.hw4, cfg.cascade_heads)
+        assert np.array_equal(n(st4["idx_c01"]), i01), f"pair {e}: upsampled window indices"
+        assert_close(n(out["messages"][12]), mo, TOL, f"pair {e}: CascadeQTAttB message (208x208)")
+        m01 = oracle.window_match(n(inp["feat_4c0"]), n(inp["feat_4c1"]), i01, cfg.cascade_temperature, mk("4c", 0), mk("4c", 1), recip=True)
+        m10 = oracle.window_match(n(inp["feat_4c1"]), n(inp["feat_4c0"]), i10, cfg.cascade_temperature, mk("4c", 1), mk("4c", 0), recip=True,
+                                  want_conf=False)
+        assert np.array_equal(n(st4["next_idx_c01"]), m01["next_idx"]), f"pair {e}: cascade argmax 0->1 (43264 x 100)"
+        assert np.array_equal(n(st4["next_idx_c10"]), m10["next_idx"]), f"pair {e}: cascade argmax 1->0"
+        assert_close(n(st4["conf_matrix"]), m01["conf_matrix"], TOL, "cascade conf_matrix")
+        so = oracle.nms_select(N(st4["next_conf_c01"][e:e + 1]), m01["next_idx"], m10["next_idx"], cfg.hw4, cfg.hw4, cfg.nms_window,
+                               cfg.cascade_test_thr, [(N(st8["next_conf_c01"][e:e + 1]), cfg.hw8, cfg.cascade_pre_thr)],
+                               cfg.cascade_border_rm, valid_hw=vh("4c"))
+        sel = N(st4["b_ids"]) == e
+        assert np.array_equal(N(st4["i_ids"])[sel], so["i_ids"]) and np.array_equal(N(st4["j_ids"])[sel], so["j_ids"]), \
+            f"pair {e}: final match list (NMS, thresholds, borders{', padding' if masked else ''}, double check)"
+        assert sel.sum() > 100
     # size-independent properties: every kept match survives its own definition
     i_ids, j_ids, b_ids = N(st4["i_ids"]), N(st4["j_ids"]), N(st4["b_ids"])
     ni01, ni10, nc01 = N(st4["next_idx_c01"]), N(st4["next_idx_c10"]), N(st4["next_conf_c01"])
@@ -192,6 +236,9 @@ def test_full_size_chain_vs_oracle(B):
     assert np.array_equal(ni10[b_ids, j_ids], i_ids), "double check"
     assert (nc01[b_ids, i_ids] > cfg.cascade_test_thr).all()
     assert (np.diff(b_ids * 10**6 + i_ids) > 0).all(), "(b,i) ordering"
+    if masked:   # no match may start or end in the padding
+        m0, m1 = N(inp["mask_4c0"]).reshape(B, -1), N(inp["mask_4c1"]).reshape(B, -1)
+        assert m0[b_ids, i_ids].all() and m1[b_ids, j_ids].all()
 
 
 def _rand(shape, seed):

@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from golden_inputs import CASES, checksum, make_inputs
-from parity_utils import assert_close, load_golden, match_set
+from parity_utils import assert_close, audit_index_mismatches, dot_score_fn, load_golden, match_set
 
 F32_SUM_TOL = 5e-5      # different fp32 summation order (torch.sum / einsum vs fmaf chain)
 SOFTMAX_TOL = 1e-4      # north_star: softmax scores within 1e-4 fp32
@@ -156,10 +156,12 @@ def test_coarse_matching(name):
                             mask0=inp["mask0"].reshape(cfg["B"], -1) if cfg.get("masks") else None,
                             mask1=inp["mask1"].reshape(cfg["B"], -1) if cfg.get("masks") else None,
                             valid_hw=valid, recip=False, want_conf=True)
-    for k in ("next_idx_c01", "next_idx_c10"):
-        bad = o[k] != g[k].astype(np.int64)
-        # fully masked rows are uniform -> argmax 0 on both sides; any other mismatch must be a near tie in conf
-        assert bad.mean() <= 1e-3, f"{k}: {bad.sum()} / {bad.size} differ"
+    # argmax indices must equal the reference's; a difference is accepted only as an audited near tie of the similarity
+    # (fully masked rows are uniform -> index 0 on both sides)
+    mk0 = inp["mask0"].reshape(cfg["B"], -1) if cfg.get("masks") else None
+    mk1 = inp["mask1"].reshape(cfg["B"], -1) if cfg.get("masks") else None
+    audit_index_mismatches(o["next_idx_c01"], g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], mk0, mk1), "next_idx_c01")
+    audit_index_mismatches(o["next_idx_c10"], g["next_idx_c10"], dot_score_fn(inp["feat1"], inp["feat0"], mk1, mk0), "next_idx_c10")
     assert_close(o["next_conf_c01"], g["next_conf_c01"], SOFTMAX_TOL, "next_conf_c01")
     assert_close(o["next_conf_c10"], g["next_conf_c10"], SOFTMAX_TOL, "next_conf_c10")
     if "conf_matrix" in g:
@@ -200,11 +202,9 @@ def test_cascade_matching(name):
     assert_close(d01["conf_matrix"], g["conf_matrix"], SOFTMAX_TOL, "conf_matrix01")
     assert_close(d01["next_conf"], g["next_conf_c01"], SOFTMAX_TOL, "next_conf_c01")
     assert_close(d10["next_conf"], g["next_conf_c10"], SOFTMAX_TOL, "next_conf_c10")
-    bad01 = d01["next_idx"] != g["next_idx_c01"].astype(np.int64)
-    bad10 = d10["next_idx"] != g["next_idx_c10"].astype(np.int64)
-    # the reference takes argmax of softmax VALUES (ties -> first), the oracle argmax of logits; on fully masked /
-    # saturated rows several window slots can share the clamped index, which is not a mismatch of the absolute index
-    assert bad01.mean() <= 2e-3 and bad10.mean() <= 2e-3, (bad01.sum(), bad10.sum())
+    # the reference takes argmax of softmax VALUES (ties -> first), the oracle argmax of logits: equal, or an audited near tie
+    audit_index_mismatches(d01["next_idx"], g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], mq, mk), "cascade next_idx_c01")
+    audit_index_mismatches(d10["next_idx"], g["next_idx_c10"], dot_score_fn(inp["feat1"], inp["feat0"], mk, mq), "cascade next_idx_c10")
     sel = oracle.nms_select(g["next_conf_c01"], g["next_idx_c01"].astype(np.int64), g["next_idx_c10"].astype(np.int64),
                             (h, w), (h, w), nms_window=5 if cfg.get("nms", True) else 0,
                             test_thr=cfg.get("test_thr", 0.2), pre=[(inp["pre_conf"], (hc, wc), cfg.get("pre_thr", 0.2))],
