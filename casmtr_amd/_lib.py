@@ -43,6 +43,7 @@ SIGNATURES = {
     "casmtr_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "casmtr_token_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_prof_enable": (None, [_I]),
+    "casmtr_debug_set": (None, [_I]),
     "casmtr_prof_enable_only": (_I, [_I]),
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),

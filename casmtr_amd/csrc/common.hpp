@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define CASMTR_WAVE 64
 #define NEG_FILL (-1e9f)  // INF = 1e9 in coarse_matching.py:6 / cascade_matching.py:8
@@ -142,7 +143,32 @@ __device__ __forceinline__ void glds_wait() {
 // every LDS read issued so far has returned (before a DMA may overwrite the buffer they read)
 __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E).  `#pragma unroll` leaves long stage loops rolled
+// (then every per-stage constant -- buffer parity, vmcnt immediates, register-array indices -- becomes a runtime value)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// sum over the lanes {l, l^8, l^16, l^32} (the 8 "slices" of a wave whose lane index is slice*8 + unit), result in every lane:
+// xor 8 by DPP row rotation, xor 16 / 32 by the gfx950 row / half swaps -- VALU only, no ds_bpermute round trips
+__device__ __forceinline__ float sum_over_slices8(float x) {
+    x += dpp_f32<0x128>(x);   // row_ror:8
+    const unsigned a = __float_as_uint(x);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const unsigned b = __float_as_uint(x);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
 // prof.hip
+extern int g_debug_flags;   // casmtr_debug_set(): phase-elimination switches for timing experiments (results become garbage)
+#define CASMTR_DBG_NO_DMA 1      // DMA kernels: do not issue / wait for the key and value row transfers
+#define CASMTR_DBG_NO_MATH 2     // DMA kernels: skip the per-stage LDS reads and arithmetic
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 struct ProfScope {

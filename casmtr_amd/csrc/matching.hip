@@ -618,7 +618,10 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
                                                                 float sqrtC, float inv_sqrtC, float T, float invT,
                                                                 float* __restrict__ conf, float* __restrict__ next_conf,
                                                                 int64_t* __restrict__ next_idx, int N, int M, int K, int h,
-                                                                int w, int nquads) {
+                                                                int w, int nquads, const int64_t* __restrict__ topk_pos,
+                                                                int w1, int dil) {
+    // topk_pos != nullptr: implicit windows (casmtr_window_match_pos_fwd) -- idx is not read; the candidate list of the quad is
+    // expanded from topk_pos [B,nquads,K/4,2] exactly as CascadeQTAttB does (modules/quadtree_attention.py:419-450)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -635,14 +638,31 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
         for (int c = lane; c < C; c += 64) qn[f * C + c] = div_scalar<RECIP>(fq[((size_t)b * N + tok[f]) * C + c], sqrtC, inv_sqrtC);
     int ci[2][4];
     bool lsame = true;
+    if (topk_pos) {
+        const int64_t* pos = topk_pos + ((size_t)b * nquads + quad) * (K >> 2) * 2;
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int p = 0; p < 2; ++p) {
             const int k = p * 64 + lane;
-            ci[p][f] = k < K ? (int)idx[((size_t)b * N + tok[f]) * K + k] : 0;
-            lsame = lsame && ci[p][f] == ci[p][0];
+            int id = 0;
+            if (k < K) {
+                const int e = k >> 2, t = k & 3;
+                long long v = (pos[2 * e] * 2 + (t >> 1) * dil) * w1 + pos[2 * e + 1] * 2 + (t & 1) * dil;
+                v = v < 0 ? 0 : (v > (long long)M - 1 ? (long long)M - 1 : v);   // torch.clamp, :429
+                id = (int)v;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) ci[p][f] = id;
         }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int k = p * 64 + lane;
+                ci[p][f] = k < K ? (int)idx[((size_t)b * N + tok[f]) * K + k] : 0;
+                lsame = lsame && ci[p][f] == ci[p][0];
+            }
+    }
     const bool same = __ballot(!lsame) == 0ull;                  // wave-uniform
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -737,7 +757,8 @@ static int launch_window_match_r(const float* fq, const float* fk, const int64_t
     if (h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N) {
         const int nquads = (h / 2) * (w / 2);
         hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3((nquads + 3) / 4, B), dim3(256), sizeof(float) * 16 * C, s, fq,
-                           fk, idx, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, h, w, nquads);
+                           fk, idx, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, N, M, K, h, w, nquads,
+                           (const int64_t*)nullptr, 0, 1);
     } else {
         const size_t lds = sizeof(float) * 4 * (CASMTR_SLAB_FLOATS + 128);
         const int nblocks = (N + 3) / 4;
@@ -767,6 +788,33 @@ extern "C" int casmtr_window_match_fwd(const float* feat_q, const float* feat_k,
     if (C == 128) return launch_window_match<128>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
     if (C == 64) return launch_window_match<64>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
     if (C == 32) return launch_window_match<32>(feat_q, feat_k, idx, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, N, M, K, h, w, s);
+    return CASMTR_ERR_UNSUPPORTED;
+}
+
+// implicit windows on the wave-per-quad kernel (window_dma.hip dispatches here by default)
+template <int C, bool RECIP>
+static int launch_wm_quad_pos(const float* fq, const float* fk, const int64_t* tp, const uint8_t* mq, const uint8_t* mk, float T,
+                              float* conf, float* next_conf, int64_t* next_idx, int B, int h0, int w0, int h1, int w1, int KW,
+                              int dil, hipStream_t s) {
+    const float sqrtC = (float)sqrt((double)C);
+    const int nquads = (h0 / 2) * (w0 / 2);
+    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
+    hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3((nquads + 3) / 4, B), dim3(256), sizeof(float) * 16 * C, s, fq, fk,
+                       (const int64_t*)nullptr, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, h0 * w0, h1 * w1,
+                       4 * KW, h0, w0, nquads, tp, w1, dil);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+int casmtr_window_match_quad_pos(const float* fq, const float* fk, const int64_t* tp, const uint8_t* mq, const uint8_t* mk, float T,
+                                 int recip, float* conf, float* next_conf, int64_t* next_idx, int B, int h0, int w0, int h1, int w1,
+                                 int KW, int C, int dil, hipStream_t s) {
+#define WMQ(CC)                                                                                                                    \
+    if (C == CC)                                                                                                                   \
+        return recip ? launch_wm_quad_pos<CC, true>(fq, fk, tp, mq, mk, T, conf, next_conf, next_idx, B, h0, w0, h1, w1, KW, dil, s) \
+                     : launch_wm_quad_pos<CC, false>(fq, fk, tp, mq, mk, T, conf, next_conf, next_idx, B, h0, w0, h1, w1, KW, dil, s);
+    WMQ(256) WMQ(128) WMQ(64) WMQ(32)
+#undef WMQ
     return CASMTR_ERR_UNSUPPORTED;
 }
 

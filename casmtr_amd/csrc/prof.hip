@@ -5,6 +5,7 @@
 #include "../../include/casmtr_hip.h"
 
 namespace casmtr {
+int g_debug_flags = 0;
 static unsigned g_mask = 0;   // bit id set: kernel id is being timed
 struct Pair { hipEvent_t a, b; };
 static std::vector<Pair> g_ev[CASMTR_PROF_COUNT];
@@ -40,6 +41,8 @@ static void prof_reset(unsigned mask) {
     }
     g_mask = mask;
 }
+
+extern "C" void casmtr_debug_set(int flags) { g_debug_flags = flags; }
 
 extern "C" void casmtr_prof_enable(int on) { prof_reset(on ? ~0u : 0u); }
 

@@ -7,10 +7,17 @@
 // [B,L/4,4,K,H] score / softmax / int64 index intermediates (:206-223) live in LDS and registers.
 // Arithmetic for anything that feeds an index: fp32 fmaf chain over d ascending, logits = fl(temp*dot), selection
 // on logits ordered (logit desc, position asc) -- identical to oracle/casmtr_oracle.c.
+#include <stdlib.h>
+#include <string.h>
 #include "common.hpp"
 #include "../../include/casmtr_hip.h"
 
 using namespace casmtr;
+
+// cascade_dma.hip
+int casmtr_cascade_attn_dma(const float* q, const float* key, const float* value, const int64_t* tp, const float* rel, float temp,
+                            int dil, float* message, int64_t* up_idx, int B, int h0, int w0, int h1, int w1, int H, int KW,
+                            hipStream_t s);
 
 // =================================================================================================== layout
 // [B,C,HW] -> [B,HW,C] for up to 9 tensors in one launch (a QTAttB call converts 3 pyramids x q,k,v).
@@ -435,6 +442,15 @@ extern "C" int casmtr_cascade_attn_fwd(const float* q, const float* key, const f
                                        casmtr_stream_t stream) {
     if (D != 32 || (h0 & 1) || (w0 & 1)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
+    // default: the wave-per-quad LDS-DMA kernel (cascade_dma.hip); CASMTR_CASCADE_KERNEL=quad selects the round-1
+    // workgroup-per-quad kernel below (also the path for shapes the DMA kernel does not cover: nhead 8, 4*KW > 128)
+    const char* ev = getenv("CASMTR_CASCADE_KERNEL");   // read per call: tests switch it
+    const bool dma = !(ev && !strcmp(ev, "quad"));
+    if (dma) {
+        const int r = casmtr_cascade_attn_dma(q, key, value, topk_pos, rel_pos, temp, dilated, message, up_idx, B, h0, w0, h1, w1,
+                                              nhead, KW, (hipStream_t)stream);
+        if (r != CASMTR_ERR_UNSUPPORTED) return r;
+    }
     QuadArgs a{};
     a.q = q; a.key = key; a.value = value; a.pidx = topk_pos; a.rel_pos = rel_pos; a.acc_in = nullptr;
     a.message = message; a.acc_out = nullptr; a.topk_score = nullptr; a.topk_idx = nullptr; a.up_idx = up_idx;

@@ -13,10 +13,17 @@
 //
 // Arithmetic is the oracle's: operands pre-scaled by 1/sqrt(C) (division or reciprocal multiply), fp32 fmaf chain over c
 // ascending, result scaled by 1/T, masked entries -1e9, argmax = first maximum of the logits.
+#include <stdlib.h>
+#include <string.h>
 #include "common.hpp"
 #include "../../include/casmtr_hip.h"
 
 using namespace casmtr;
+
+// matching.hip
+int casmtr_window_match_quad_pos(const float* fq, const float* fk, const int64_t* tp, const uint8_t* mq, const uint8_t* mk, float T,
+                                 int recip, float* conf, float* next_conf, int64_t* next_idx, int B, int h0, int w0, int h1, int w1,
+                                 int KW, int C, int dil, hipStream_t s);
 
 // candidate k of a quad: parent e = k / 4 (window cell), child t = k % 4 -> (row + t/2 * dil, col + t%2 * dil) on the fine grid,
 // clamped like torch.clamp at modules/quadtree_attention.py:429
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(128) void window_match_pos_kernel(
     const float* __restrict__ fq, const float* __restrict__ fk, const int64_t* __restrict__ topk_pos,
     const uint8_t* __restrict__ mq, const uint8_t* __restrict__ mk, float sqrtC, float inv_sqrtC, float T, float invT,
     float* __restrict__ conf, float* __restrict__ next_conf, int64_t* __restrict__ next_idx, int h0, int w0, int h1, int w1,
-    int KW, int dil, int nquads) {
+    int KW, int dil, int nquads, int dbg) {
     constexpr int NCH = C / 32, NPASS = NP1 > 0 ? 2 : 1, NS = NCH * NPASS;
     constexpr int WAVE_FLOATS = 4 * C + 2 * 2048;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -100,17 +107,20 @@ __global__ __launch_bounds__(128) void window_match_pos_kernel(
         for (int j = 0; j < (p == 0 ? 8 : NP1); ++j)
             glds16(kb, roff[p][j] + (unsigned)(ch * 128), buf_lds + (unsigned)((s & 1) * 8192 + j * 1024));
     };
-    issue(0);
+    const bool no_dma = dbg & CASMTR_DBG_NO_DMA, no_math = dbg & CASMTR_DBG_NO_MATH;
+    if (!no_dma) issue(0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int ch = s / NPASS, p = s % NPASS;
-        if (s + 1 < NS) {
+        if (no_dma) {
+        } else if (s + 1 < NS) {
             lds_reads_done();          // the reads of stage s-1 (same buffer as stage s+1) have returned
             issue(s + 1);
             if ((s + 1) % NPASS == 0) glds_wait<8>(); else glds_wait<NP1>();   // everything but stage s+1 has landed
         } else {
             glds_wait<0>();
         }
+        if (no_math) continue;
         const char* bp = reinterpret_cast<const char*>(buf) + (s & 1) * 8192;
         f32x4 kr[8];
 #pragma unroll
@@ -183,7 +193,7 @@ static int launch_wm_pos(const float* fq, const float* fk, const int64_t* tp, co
     const size_t lds = sizeof(float) * 2 * (4 * C + 2 * 2048);
     ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
     hipLaunchKernelGGL((window_match_pos_kernel<C, RECIP, NP1>), dim3((nquads + 1) / 2, B), dim3(128), lds, s, fq, fk, tp, mq, mk,
-                       sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, h0, w0, h1, w1, KW, dil, nquads);
+                       sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, h0, w0, h1, w1, KW, dil, nquads, g_debug_flags);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -205,6 +215,14 @@ extern "C" int casmtr_window_match_pos_fwd(const float* feat_q, const float* fea
     if (KW <= 0 || 4 * KW > 128 || (h0 & 1) || (w0 & 1) || (mask_q == nullptr) != (mask_k == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    // default: the round-1 wave-per-quad kernel (matching.hip) with the candidate list expanded from topk_pos in registers.
+    // CASMTR_WINDOW_KERNEL=dma selects the LDS-DMA staged kernel of this file: measured 0.64 ms per launch against 0.59
+    // (8 waves per CU cannot cover its per-quad prologue / epilogue latencies: DESIGN.md section 8, round 2)
+    const char* ev = getenv("CASMTR_WINDOW_KERNEL");   // read per call: tests switch it
+    const bool dma = ev && !strcmp(ev, "dma");
+    if (!dma)
+        return casmtr_window_match_quad_pos(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx,
+                                            B, h0, w0, h1, w1, KW, C, dilated, s);
 #define WM_CASE(CC)                                                                                                              \
     if (C == CC)                                                                                                                 \
         return recip ? dispatch_wm_pos_k<CC, true>(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, conf, next_conf,      \

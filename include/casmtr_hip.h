@@ -180,6 +180,9 @@ enum {
     CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
+/* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).
+ * Any non-zero value makes their results meaningless; 0 (default) is the product behaviour.                              */
+void casmtr_debug_set(int flags);
 /* fresh collection that times ONLY kernel `id` (two event records per launch of that kernel, none for the others) */
 int casmtr_prof_enable_only(int id);
 int casmtr_prof_read(int id, double* total_ms, int* count);

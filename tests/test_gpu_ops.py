@@ -125,8 +125,10 @@ def test_qtattb_levels(ops, name):
     assert_close(N(acc), g["final"], SOFTMAX_TOL, "final message vs reference python")
 
 
+@pytest.mark.parametrize("kernel", ["dma", "quad"])
 @pytest.mark.parametrize("name", list(CASES["cascade_attn"]))
-def test_cascade_attn(ops, name):
+def test_cascade_attn(ops, monkeypatch, name, kernel):
+    monkeypatch.setenv("CASMTR_CASCADE_KERNEL", kernel)   # default persistent LDS-DMA + MFMA kernel | round-1 workgroup-per-quad kernel
     inp = make_inputs("cascade_attn", name)
     cfg = CASES["cascade_attn"][name]
     g = load_golden("cascade_attn", name)
@@ -334,12 +336,14 @@ def test_coarse_topk_paths(ops, kind):
     assert_close(N(out["topk_score"]), o[1], SOFTMAX_TOL, "topk_score")
 
 
+@pytest.mark.parametrize("kernel", ["quad", "dma"])
 @pytest.mark.parametrize("recip", [False, True])
 @pytest.mark.parametrize("C,ws,masks,dil", [(128, 5, False, 1), (128, 5, True, 1), (64, 5, False, 1), (128, 3, False, 1),
                                             (256, 5, False, 1), (32, 5, True, 2)])
-def test_window_match_implicit_windows(ops, C, ws, masks, dil, recip):
+def test_window_match_implicit_windows(ops, monkeypatch, C, ws, masks, dil, recip, kernel):
     """casmtr_window_match_pos_fwd (topk_pos in, candidates expanded in-kernel, LDS-DMA key staging) == the explicit-index
     kernel == the oracle on the expanded tensor; casmtr_window_expand_idx == CascadeQTAttB's upsampled_idx."""
+    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", kernel)   # default wave-per-quad kernel | LDS-DMA staged kernel
     B, hc, wc = 2, 12, 16
     h, w = 2 * hc, 2 * wc
     r = np.random.default_rng(100 + C + ws)

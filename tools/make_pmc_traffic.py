@@ -11,7 +11,8 @@ import sys
 from collections import defaultdict
 
 BENCH_NAME = [("quad_attn_kernel<8, 64, 0>", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 128, 0>", "quad_attn_kernel<fine>"),
-              ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("window_match", "window_match_kernel"),
+              ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
+              ("coarse_fused_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
               ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
               ("nchw_to_tokens_kernel", "nchw_to_tokens_kernel"), ("coarse_row_kernel", "coarse_row_kernel"),
               ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel"),
