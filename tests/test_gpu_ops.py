@@ -97,9 +97,11 @@ def _tok(x):
     return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(B, h * w, C))
 
 
+@pytest.mark.parametrize("kernel", ["dma", "quad"])
 @pytest.mark.parametrize("name", list(CASES["qtattb"]))
-def test_qtattb_levels(ops, name):
+def test_qtattb_levels(ops, monkeypatch, name, kernel):
     """coarse + fine level kernels chained exactly like QTAttB.forward; indices bit-exact vs oracle AND vs the reference."""
+    monkeypatch.setenv("CASMTR_FINE_KERNEL", kernel)   # default persistent LDS-DMA + MFMA kernel | round-1 workgroup-per-quad kernel
     inp = make_inputs("qtattb", name)
     cfg = CASES["qtattb"][name]
     H, topks = cfg["nhead"], cfg["topks"]
@@ -273,6 +275,31 @@ def test_fine_level_wide_candidate_lists(ops, H, Kp, topk):
     out = ops.qta_fine_level(T(q), T(k), T(v), T(prev.astype(np.int64)), (h0, w0), (h1, w1), H, topk, w_level=0.37, acc_in=T(acc_in))
     assert np.array_equal(N(out["topk_idx"]), o["topk_idx"])
     assert_close(N(out["topk_score"]), o["topk_score"], SOFTMAX_TOL, "topk_score")
+    assert_close(N(out["acc"]), o["acc"], SOFTMAX_TOL, "merged message")
+
+
+@pytest.mark.parametrize("H,Kp,topk,with_acc", [(8, 16, 8, True), (8, 32, 16, True), (8, 16, 0, True), (4, 32, 16, False), (2, 9, 5, True),
+                                                 (1, 16, 4, True), (4, 5, 20, True)])
+def test_fine_level_dma_kernel_shapes(ops, H, Kp, topk, with_acc):
+    """fine_level_dma_kernel (K = 4*Kp <= 128): every head count / XCD split, ragged candidate counts, top-k == K, no top-k (finest
+    level), no incoming accumulator, query grid != key grid, several pairs -- top-k bit-exact, messages within tolerance"""
+    r = np.random.default_rng(1000 * H + 10 * Kp + topk)
+    B, (h0, w0), (h1, w1) = 3, (12, 20), (16, 12)
+    C = H * 32
+    q = r.standard_normal((B, h0 * w0, C)).astype(np.float32)
+    k = r.standard_normal((B, h1 * w1, C)).astype(np.float32)
+    v = r.standard_normal((B, h1 * w1, C)).astype(np.float32)
+    Lq, Sp = (h0 // 2) * (w0 // 2), (h1 // 2) * (w1 // 2)
+    prev = np.stack([np.stack([r.permutation(Sp)[:Kp] for _ in range(H)], -1) for _ in range(B * Lq)]).reshape(B, Lq, Kp, H)
+    acc_in = r.standard_normal((B, Lq, H, 32)).astype(np.float32) if with_acc else None
+    o = oracle.qta_fine_level(q.reshape(B, -1, H, 32), k.reshape(B, -1, H, 32), v.reshape(B, -1, H, 32), prev, (h0, w0), (h1, w1),
+                              topk, 0.37, acc_in)
+    out = ops.qta_fine_level(T(q), T(k), T(v), T(prev.astype(np.int64)), (h0, w0), (h1, w1), H, topk, w_level=0.37,
+                             acc_in=None if acc_in is None else T(acc_in))
+    if topk:
+        assert np.array_equal(N(out["topk_idx"]), o["topk_idx"])
+        assert_close(N(out["topk_score"]), o["topk_score"], SOFTMAX_TOL, "topk_score")
+    assert_close(N(out["message"]), o["message"], SOFTMAX_TOL, "message")
     assert_close(N(out["acc"]), o["acc"], SOFTMAX_TOL, "merged message")
 
 
