@@ -36,152 +36,251 @@ __device__ __forceinline__ int window_candidate(const int64_t* __restrict__ pos,
     return (int)id;
 }
 
-// One WAVE per quad of query tokens, 2 quads per workgroup, no block-level synchronisation.
-// lane <-> candidates k = lane (pass 0) and 64 + lane (pass 1).  Stage (ch, p) = 32 channels of the 64 candidate rows of
-// pass p: 8 (pass 1: NP1) DMA instructions into buffer (stage & 1), issued one stage ahead of the arithmetic.
+// One WAVE per quad of query tokens, persistent (a wave walks its share of the quads; every XCD one contiguous range of quads
+// per pair), 2 waves per workgroup, no block-level synchronisation.  lane <-> candidates k = lane (pass 0) and 64 + lane (pass
+// 1).  Stage (ch, p) = 32 channels of the 64 candidate rows of pass p: 8 (pass 1: NP1) DMA instructions into buffer (stage & 1),
+// issued one stage ahead of the arithmetic, across quads.  The arithmetic of a stage: 8 conflict-free ds_read_b128 bring the
+// lane's row chunk back, it is pre-scaled (1/sqrt(C)) and goes through 32 v_mfma_f32_4x4x1_16B_f32 -- operand A: the 4 children's
+// pre-scaled query channel (the same 4 values in every block), operand B: the lane-per-candidate rows; a c-sequence of them is the
+// exact c-ascending fmaf chain (tools/probes/mfma4x4_layout.hip), carried across the chunks in the accumulator.
 template <int C, bool RECIP, int NP1>
-__global__ __launch_bounds__(128) void window_match_pos_kernel(
+__global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
     const float* __restrict__ fq, const float* __restrict__ fk, const int64_t* __restrict__ topk_pos,
     const uint8_t* __restrict__ mq, const uint8_t* __restrict__ mk, float sqrtC, float inv_sqrtC, float T, float invT,
-    float* __restrict__ conf, float* __restrict__ next_conf, int64_t* __restrict__ next_idx, int h0, int w0, int h1, int w1,
+    float* __restrict__ conf, float* __restrict__ next_conf, int64_t* __restrict__ next_idx, int B, int h0, int w0, int h1, int w1,
     int KW, int dil, int nquads, int dbg) {
     constexpr int NCH = C / 32, NPASS = NP1 > 0 ? 2 : 1, NS = NCH * NPASS;
-    constexpr int WAVE_FLOATS = 4 * C + 2 * 2048;
+    constexpr int QV = (C + 255) / 256;                        // float4s of a child's query row per lane
+    constexpr int WAVE_FLOATS = 4 * C + 2 * 64 + 2 * 2048;   // queries [4][C] | window positions [parity][32][2] | 2 x [64 rows][32]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* qn = smem + wave * WAVE_FLOATS;       // [4 children][C] normalised queries
-    float* buf = qn + 4 * C;                      // 2 x [64 rows][32 floats]
-    const int b = blockIdx.y;
-    const int quad = xcd_chunk_remap(blockIdx.x, gridDim.x) * 2 + wave;   // neighbouring quads (overlapping windows) share an L2
-    if (quad >= nquads) return;
-    const int N = h0 * w0, S = h1 * w1, K = 4 * KW;
-    const int wq = w0 >> 1, qy = quad / wq, qx = quad % wq;
-    int tok[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) tok[f] = (2 * qy + (f >> 1)) * w0 + 2 * qx + (f & 1);
-    const int64_t* pos = topk_pos + ((size_t)b * nquads + quad) * KW * 2;
-    const int c0 = window_candidate(pos, lane, K, w1, S, dil);
-    const int c1 = window_candidate(pos, 64 + lane, K, w1, S, dil);
-    // DMA source offsets (bytes from the pair's key base): instruction j moves local rows 8j .. 8j+7, lane -> (row 8j + lane/8,
-    // physical 16-byte unit lane%8).  Physical unit p of local row r holds logical unit p ^ ((r >> 1) & 7): with 128-byte rows
-    // that makes the ds_read_b128 of "lane reads unit u of row lane" hit 16 different units in every 16-lane group.
-    unsigned roff[NPASS][8];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-        for (int j = 0; j < (p == 0 ? 8 : NP1); ++j) {
-            const int r = 8 * j + (lane >> 3);
-            const int row = window_candidate(pos, 64 * p + r, K, w1, S, dil);
-            roff[p][j] = (unsigned)row * (C * 4) + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-        }
+    float* qn = smem + wave * WAVE_FLOATS;
+    int* ptab = reinterpret_cast<int*>(qn + 4 * C);
+    float* buf = reinterpret_cast<float*>(ptab + 2 * 64);
+    const int N = h0 * w0, S = h1 * w1, K = 4 * KW, wq = w0 >> 1;
+    const int xcd = blockIdx.x & 7, chunk = (nquads + 7) >> 3;
+    const int cnt = min(chunk, nquads - xcd * chunk);
+    const int total = cnt > 0 ? B * cnt : 0, stride = (gridDim.x >> 3) * 2;
+    const int t0 = (blockIdx.x >> 3) * 2 + wave;
+    if (t0 >= total) return;
+    const unsigned buf_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(buf));
+    const int sl = lane >> 3, un = lane & 7;
+    const unsigned swz[2] = {(unsigned)((un ^ (lane >> 4)) * 16), (unsigned)((un ^ (4 + (lane >> 4))) * 16)};   // DMA instr j even / odd
     unsigned rd[8];   // read side: byte offset of logical unit u in this lane's row
 #pragma unroll
     for (int u = 0; u < 8; ++u) rd[u] = (unsigned)(lane * 128 + ((u ^ ((lane >> 1) & 7)) * 16));
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-        for (int c = lane; c < C; c += 64) qn[f * C + c] = div_scalar<RECIP>(fq[((size_t)b * N + tok[f]) * C + c], sqrtC, inv_sqrtC);
-    int mqv[4] = {1, 1, 1, 1};
-    int mk0 = 1, mk1 = 1;
-    if (mq) {   // fetched before any DMA is outstanding (compiler-generated loads must not share the vmcnt window)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) mqv[f] = mq[(size_t)b * N + tok[f]];
-        mk0 = mk[(size_t)b * S + c0];
-        mk1 = mk[(size_t)b * S + c1];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every ordinary load above has landed
-    const float* kb = fk + (size_t)b * S * C;
-    const unsigned buf_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(buf));
-    float acc[NPASS][4];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[p][f] = 0.f;
+    const bool no_dma = dbg & CASMTR_DBG_NO_DMA, no_math = dbg & CASMTR_DBG_NO_MATH;
+    const bool qlane = lane * 4 < C;
 
-    auto issue = [&](int s) {   // s is a compile-time constant at every call site (the loop below is fully unrolled)
-        const int ch = s / NPASS, p = s % NPASS;
+    struct Item { int b, quad, l00; };   // pair, quad, first child's token (child f -> l00 + (f>>1)*w0 + (f&1))
+    int cb = t0 / cnt, cq = t0 % cnt, cy = (xcd * chunk + cq) / wq, cx = (xcd * chunk + cq) % wq;
+    const int sy = stride / wq, sx = stride % wq;
+    auto take = [&](Item& it) {
+        if (cb >= B) return false;
+        it.b = cb; it.quad = xcd * chunk + cq; it.l00 = 2 * cy * w0 + 2 * cx;
+        cq += stride;
+        if (cq >= cnt) {
+            while (cq >= cnt) { cq -= cnt; ++cb; }
+            cy = (xcd * chunk + cq) / wq; cx = (xcd * chunk + cq) % wq;
+        } else {
+            cy += sy; cx += sx;
+            if (cx >= wq) { cx -= wq; ++cy; }
+        }
+        return true;
+    };
+    // front end, one quad ahead: global -> registers (prefetch), registers -> LDS + DMA row offsets + masks (stage_in)
+    long long pf_y = 0, pf_x = 0;
+    f32x4 pf_q[4][QV];
+    int pf_mq = 1;
+    auto prefetch = [&](const Item& it) {
+        if (lane < KW) {
+            const int64_t* pp = topk_pos + (((size_t)it.b * nquads + it.quad) * KW + lane) * 2;
+            pf_y = pp[0]; pf_x = pp[1];
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int i = 0; i < QV; ++i)
+                if (qlane || i + 1 < QV)
+                    pf_q[f][i] = *reinterpret_cast<const f32x4*>(fq + ((size_t)it.b * N + it.l00 + (f >> 1) * w0 + (f & 1)) * C + (i * 64 + lane) * 4);
+        if (mq && lane < 4) pf_mq = mq[(size_t)it.b * N + it.l00 + (lane >> 1) * w0 + (lane & 1)];
+    };
+    unsigned rowb[NPASS][8];
+    int cnd_nx[2] = {0, 0}, mk_nx[2] = {1, 1}, mq_nx = 1;   // staged for the next quad: own candidates, their masks, the children's masks
+    f32x4 q_nx[4][QV];
+    auto put_queries = [&]() {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int i = 0; i < QV; ++i)
+                if (qlane || i + 1 < QV) *reinterpret_cast<f32x4*>(qn + f * C + (i * 64 + lane) * 4) = q_nx[f][i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto stage_in = [&](const Item& it, int par) {
+        int* pt = ptab + par * 64;
+        if (lane < KW) { pt[2 * lane] = (int)pf_y; pt[2 * lane + 1] = (int)pf_x; }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int i = 0; i < QV; ++i) {   // pre-scaled queries wait in registers until the current quad's last stage has read qn
+                f32x4 v = pf_q[f][i];
+                v.x = div_scalar<RECIP>(v.x, sqrtC, inv_sqrtC); v.y = div_scalar<RECIP>(v.y, sqrtC, inv_sqrtC);
+                v.z = div_scalar<RECIP>(v.z, sqrtC, inv_sqrtC); v.w = div_scalar<RECIP>(v.w, sqrtC, inv_sqrtC);
+                q_nx[f][i] = v;
+            }
+        mq_nx = pf_mq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // candidate k: parent e = k / 4 (window cell), child c = k % 4 -> (row + c/2 * dil, col + c%2 * dil), clamped (:419-429)
+        auto candidate = [&](int k) {
+            const int kk = k < K ? k : K - 1;
+            const int e = kk >> 2, c = kk & 3;
+            const int id = (pt[2 * e] * 2 + (c >> 1) * dil) * w1 + pt[2 * e + 1] * 2 + (c & 1) * dil;   // grid coordinates: fits 32 bits
+            return id < 0 ? 0 : (id > S - 1 ? S - 1 : id);
+        };
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int j = 0; j < (p == 0 ? 8 : NP1); ++j) rowb[p][j] = (unsigned)candidate(64 * p + 8 * j + sl) * (C * 4);
+        cnd_nx[0] = candidate(lane);
+        cnd_nx[1] = candidate(64 + lane);
+        if (mq) {
+            mk_nx[0] = mk[(size_t)it.b * S + cnd_nx[0]];
+            mk_nx[1] = mk[(size_t)it.b * S + cnd_nx[1]];
+        }
+    };
+    auto issue = [&](auto sc, int b) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int ch = s / NPASS, p = s % NPASS;
+        const float* base = fk + (size_t)b * S * C + ch * 32;   // wave-uniform: scalar arithmetic
 #pragma unroll
         for (int j = 0; j < (p == 0 ? 8 : NP1); ++j)
-            glds16(kb, roff[p][j] + (unsigned)(ch * 128), buf_lds + (unsigned)((s & 1) * 8192 + j * 1024));
+            glds16(base, rowb[p][j] + swz[j & 1], buf_lds + (unsigned)((s & 1) * 8192 + j * 1024));
     };
-    const bool no_dma = dbg & CASMTR_DBG_NO_DMA, no_math = dbg & CASMTR_DBG_NO_MATH;
-    if (!no_dma) issue(0);
+    // results of the previous quad, stored one stage late (right behind a DMA wait: vmcnt counts stores too, in order)
+    float pe[4][2] = {}, pnc[4] = {};
+    int pam[4] = {}, pcnd[2] = {0, 0}, pend_b = 0, pend_l00 = 0;
+    bool have_pend = false;
+    auto flush = [&]() {
+        if (have_pend) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int ch = s / NPASS, p = s % NPASS;
-        if (no_dma) {
-        } else if (s + 1 < NS) {
-            lds_reads_done();          // the reads of stage s-1 (same buffer as stage s+1) have returned
-            issue(s + 1);
-            if ((s + 1) % NPASS == 0) glds_wait<8>(); else glds_wait<NP1>();   // everything but stage s+1 has landed
-        } else {
-            glds_wait<0>();
+            for (int f = 0; f < 4; ++f) {
+                const size_t n = (size_t)pend_b * N + pend_l00 + (f >> 1) * w0 + (f & 1);
+                if (conf) {
+                    if (lane < K) conf[n * K + lane] = pe[f][0];
+                    if (64 + lane < K) conf[n * K + 64 + lane] = pe[f][1];
+                }
+                if (lane == (pam[f] & 63)) {
+                    next_conf[n] = pnc[f];
+                    next_idx[n] = pam[f] < 64 ? pcnd[0] : pcnd[1];
+                }
+            }
         }
-        if (no_math) continue;
-        const char* bp = reinterpret_cast<const char*>(buf) + (s & 1) * 8192;
-        f32x4 kr[8];
+        have_pend = false;
+    };
+
+    Item it_cur{}, it_nx{}, it_pf{};
+    take(it_cur);
+    prefetch(it_cur);
+    stage_in(it_cur, 0);
+    put_queries();
+    int cnd[2] = {cnd_nx[0], cnd_nx[1]}, mkv[2] = {mk_nx[0], mk_nx[1]}, mqv = mq_nx;
+    int par = 0;
+    if (!no_dma) issue(std::integral_constant<int, 0>{}, it_cur.b);
+    bool more = take(it_nx), has_pf = false;
+    if (more) prefetch(it_nx);
+    for (;; par ^= 1) {
+        const float* qp = qn;
+        f32x4 acc[NPASS], qa[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(bp + rd[u]);
+        for (int p = 0; p < NPASS; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        static_for<0, NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int ch = s / NPASS, p = s % NPASS;
+            if constexpr (s == NS - 1) {
+                if (more) stage_in(it_nx, par ^ 1);   // the next quad's front end, then its stage 0, under this quad's last stage
+            }
+            if (!no_dma) {
+                lds_reads_done();
+                if constexpr (s + 1 < NS) {
+                    issue(std::integral_constant<int, s + 1>{}, it_cur.b);
+                    glds_wait<((s + 1) % NPASS == 0) ? 8 : NP1>();
+                } else {
+                    if (more) { issue(std::integral_constant<int, 0>{}, it_nx.b); glds_wait<8>(); }
+                    else glds_wait<0>();
+                }
+            }
+            if constexpr (s == 0) flush();
+            if constexpr (s == NS - 1) {
+                has_pf = more && take(it_pf);
+                if (has_pf) prefetch(it_pf);   // behind the wait: a whole quad's time before stage_in consumes it
+            }
+            if (no_math) return;
+            const char* bp = reinterpret_cast<const char*>(buf) + (s & 1) * 8192;
+            f32x4 kr[8];          // operand B: this lane's candidate row chunk; operand A (qa): lane l holds qn[child l%4][c]
+            if constexpr (p == 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            kr[u].x = div_scalar<RECIP>(kr[u].x, sqrtC, inv_sqrtC); kr[u].y = div_scalar<RECIP>(kr[u].y, sqrtC, inv_sqrtC);
-            kr[u].z = div_scalar<RECIP>(kr[u].z, sqrtC, inv_sqrtC); kr[u].w = div_scalar<RECIP>(kr[u].w, sqrtC, inv_sqrtC);
-        }
+                for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qp + (lane & 3) * C + ch * 32 + 4 * u);
+            }
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const f32x4* qp = reinterpret_cast<const f32x4*>(qn + f * C + ch * 32);   // broadcast reads
-            float a = acc[p][f];
+            for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(bp + rd[u]);
+            lds_reads_done();
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const f32x4 qv = qp[u];
-                a = __builtin_fmaf(qv.x, kr[u].x, a);
-                a = __builtin_fmaf(qv.y, kr[u].y, a);
-                a = __builtin_fmaf(qv.z, kr[u].z, a);
-                a = __builtin_fmaf(qv.w, kr[u].w, a);
+                kr[u].x = div_scalar<RECIP>(kr[u].x, sqrtC, inv_sqrtC); kr[u].y = div_scalar<RECIP>(kr[u].y, sqrtC, inv_sqrtC);
+                kr[u].z = div_scalar<RECIP>(kr[u].z, sqrtC, inv_sqrtC); kr[u].w = div_scalar<RECIP>(kr[u].w, sqrtC, inv_sqrtC);
             }
-            acc[p][f] = a;
-        }
-        // pin this stage's arithmetic in front of the next stage's asm statements: hipcc otherwise keeps only the LDS reads in
-        // place (the asm "memory" clobbers order those), parks their results in scratch and runs every fmaf at the very end
+            f32x4 a = acc[p];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(acc[p][f]));
-    }
-    // softmax over the K candidates, first argmax of the logits (cascade_matching.py:119-149)
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int n = tok[f];
-        float x[2] = {0.f, 0.f};
-        unsigned key[2] = {0u, 0u};
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int k = p * 64 + lane;
-            if (k < K) {
-                float v = div_scalar<RECIP>(acc[p][f], T, invT);
-                if (mq && !(mqv[f] && (p ? mk1 : mk0))) v = NEG_FILL;
-                x[p] = v; key[p] = f2ord(v);
+            for (int u = 0; u < 8; ++u) {
+                a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, a, 0, 0, 0);
             }
+            acc[p] = a;
+            asm volatile("" : "+v"(acc[p]));   // keep the stage's arithmetic inside the stage
+        });
+        // softmax over the K candidates, first argmax of the logits (cascade_matching.py:119-149); stores deferred to flush()
+        if (!no_math) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int mqf = __builtin_amdgcn_readlane(mqv, f);
+                float x[2] = {0.f, 0.f};
+                unsigned key[2] = {0u, 0u};
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) {
+                    const int k = p * 64 + lane;
+                    if (k < K) {
+                        float v = div_scalar<RECIP>(acc[p][f], T, invT);
+                        if (mq && !(mqf && mkv[p])) v = NEG_FILL;
+                        x[p] = v; key[p] = f2ord(v);
+                    }
+                }
+                const unsigned wm = wave_max_u32(max(key[0], key[1]));
+                const float m = ord2f(wm);
+                float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
+                float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
+                const float sm = wave_sum_f32(e0 + e1);
+                e0 = e0 / sm; e1 = e1 / sm;
+                const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
+                const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
+                const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+                pe[f][0] = e0; pe[f][1] = e1; pam[f] = am; pnc[f] = am < 64 ? e0 : e1;
+            }
+            pcnd[0] = cnd[0]; pcnd[1] = cnd[1]; pend_b = it_cur.b; pend_l00 = it_cur.l00; have_pend = true;
         }
-        const unsigned wm = wave_max_u32(max(key[0], key[1]));
-        const float m = ord2f(wm);
-        float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
-        float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
-        const float sm = wave_sum_f32(e0 + e1);
-        e0 = e0 / sm; e1 = e1 / sm;
-        if (conf) {
-            if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
-            if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
-        }
-        const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
-        const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
-        const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
-        if (lane == (am & 63)) {
-            next_conf[(size_t)b * N + n] = am < 64 ? e0 : e1;
-            next_idx[(size_t)b * N + n] = am < 64 ? c0 : c1;
-        }
+        lds_reads_done();
+        if (!more) break;
+        put_queries();
+        cnd[0] = cnd_nx[0]; cnd[1] = cnd_nx[1]; mkv[0] = mk_nx[0]; mkv[1] = mk_nx[1]; mqv = mq_nx;
+        it_cur = it_nx; it_nx = it_pf; more = has_pf;
     }
+    flush();
 }
 
 template <int C, bool RECIP, int NP1>
@@ -190,10 +289,22 @@ static int launch_wm_pos(const float* fq, const float* fk, const int64_t* tp, co
                          hipStream_t s) {
     const float sqrtC = (float)sqrt((double)C);
     const int nquads = (h0 / 2) * (w0 / 2);
-    const size_t lds = sizeof(float) * 2 * (4 * C + 2 * 2048);
+    const size_t lds = sizeof(float) * 2 * (4 * C + 2 * 64 + 2 * 2048);
+    static int resident = 0;   // persistent grid: exactly the workgroups that are resident at once
+    if (!resident) {
+        int dev = 0, ncu = 0, per_cu = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, window_match_pos_kernel<C, RECIP, NP1>, 128, lds);
+        if (e != hipSuccess || ncu <= 0 || per_cu <= 0) return e != hipSuccess ? (int)e : CASMTR_ERR_UNSUPPORTED;
+        resident = ncu * per_cu / 8 * 8;
+    }
+    const long long work = (long long)B * nquads;
+    long long blocks = resident;
+    if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
     ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
-    hipLaunchKernelGGL((window_match_pos_kernel<C, RECIP, NP1>), dim3((nquads + 1) / 2, B), dim3(128), lds, s, fq, fk, tp, mq, mk,
-                       sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, h0, w0, h1, w1, KW, dil, nquads, g_debug_flags);
+    hipLaunchKernelGGL((window_match_pos_kernel<C, RECIP, NP1>), dim3((unsigned)blocks), dim3(128), lds, s, fq, fk, tp, mq, mk, sqrtC,
+                       1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, B, h0, w0, h1, w1, KW, dil, nquads, g_debug_flags);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -215,12 +326,11 @@ extern "C" int casmtr_window_match_pos_fwd(const float* feat_q, const float* fea
     if (KW <= 0 || 4 * KW > 128 || (h0 & 1) || (w0 & 1) || (mask_q == nullptr) != (mask_k == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // default: the round-1 wave-per-quad kernel (matching.hip) with the candidate list expanded from topk_pos in registers.
-    // CASMTR_WINDOW_KERNEL=dma selects the LDS-DMA staged kernel of this file: measured 0.64 ms per launch against 0.59
-    // (8 waves per CU cannot cover its per-quad prologue / epilogue latencies: DESIGN.md section 8, round 2)
-    const char* ev = getenv("CASMTR_WINDOW_KERNEL");   // read per call: tests switch it
-    const bool dma = ev && !strcmp(ev, "dma");
-    if (!dma)
+    // default: the persistent LDS-DMA + MFMA kernel of this file (0.46 ms per launch at 208x208, C = 128, B = 8);
+    // CASMTR_WINDOW_KERNEL=quad selects the round-1 wave-per-quad kernel (matching.hip) with the candidate list expanded from
+    // topk_pos in registers (0.55 ms).  Read per call: tests switch it.
+    const char* ev = getenv("CASMTR_WINDOW_KERNEL");
+    if (ev && !strcmp(ev, "quad"))
         return casmtr_window_match_quad_pos(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx,
                                             B, h0, w0, h1, w1, KW, C, dilated, s);
 #define WM_CASE(CC)                                                                                                              \

@@ -370,7 +370,7 @@ def test_coarse_topk_paths(ops, kind):
 def test_window_match_implicit_windows(ops, monkeypatch, C, ws, masks, dil, recip, kernel):
     """casmtr_window_match_pos_fwd (topk_pos in, candidates expanded in-kernel, LDS-DMA key staging) == the explicit-index
     kernel == the oracle on the expanded tensor; casmtr_window_expand_idx == CascadeQTAttB's upsampled_idx."""
-    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", kernel)   # default wave-per-quad kernel | LDS-DMA staged kernel
+    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", kernel)   # round-1 wave-per-quad kernel | default persistent LDS-DMA + MFMA kernel
     B, hc, wc = 2, 12, 16
     h, w = 2 * hc, 2 * wc
     r = np.random.default_rng(100 + C + ws)
