@@ -144,7 +144,7 @@ __global__ __launch_bounds__(128, 2) void cascade_attn_dma_kernel(
         if (t + stride < total) prefetch(t + stride);   // lands while the stages below run; consumed at the top of the next iteration
 
         f32x4 lg[NPASS];           // logits of candidate 64p + lane for the 4 children
-        f32x4 acc[2];
+        f32x4 acc[4];
         static_for<0, NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int h = s / (2 * NPASS), isv = (s / NPASS) & 1, p = s % NPASS;
@@ -165,14 +165,22 @@ __global__ __launch_bounds__(128, 2) void cascade_attn_dma_kernel(
                 for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * HD + h * 32 + 4 * u);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(bp + rd[u]);
-                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // The logits feed a softmax only (no index depends on them), so the d-sum need not be the sequential chain: four
+                // interleaved partial chains (d = 4u + c -> chain c) keep the matrix pipe busy -- a dependent v_mfma_f32_4x4x1
+                // waits ~28 cycles for its accumulator (PMC: SQ_WAIT_INST_ANY = 30 % of the wave cycles with one chain)
+                f32x4 a4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a4[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, a, 0, 0, 0);
+                    a4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, a4[0], 0, 0, 0);
+                    a4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, a4[1], 0, 0, 0);
+                    a4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, a4[2], 0, 0, 0);
+                    a4[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, a4[3], 0, 0, 0);
                 }
+                f32x4 a;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) a[f] = (a4[0][f] + a4[1][f]) + (a4[2][f] + a4[3][f]);
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     float x = temp * a[f];
@@ -207,19 +215,19 @@ __global__ __launch_bounds__(128, 2) void cascade_attn_dma_kernel(
             } else {
                 // ---- message += A . V over this pass's rows, two rows per instruction
                 if constexpr (p == 0) {
-                    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 const float* vrow = reinterpret_cast<const float*>(bp) + lane;                       // + 64 m : rows 2m | 2m+1
                 const float* prow = Ald + (64 * p + (lane >> 5)) * 4 + (lane & 3);                  // + 8 m  : P[row][child lane%4]
 #pragma unroll
                 for (int m = 0; m < (p == 0 ? 32 : NP1 * 4); ++m)
-                    acc[m & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(prow[8 * m], vrow[64 * m], acc[m & 1], 0, 0, 0);
+                    acc[m & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(prow[8 * m], vrow[64 * m], acc[m & 3], 0, 0, 0);
                 if constexpr (p == NPASS - 1) {
                     f32x4 tot;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float x = acc[0][c] + acc[1][c];
+                        const float x = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
                         const unsigned xi = __float_as_uint(x);
                         const auto sw = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);   // lanes l and l ^ 32
                         tot[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(128, 2) void cascade_attn_dma_kernel(
                             message[((size_t)b * L + l00 + (f >> 1) * w0 + (f & 1)) * HD + h * 32 + lane] = tot[f];
                     }
                 } else {
-                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
                 }
             }
         });

@@ -38,7 +38,7 @@ struct FineArgs {
     int topk, B, h0, w0, h1, w1, H, Kp, nquads, dbg;
 };
 
-template <int NPASS>
+template <int NPASS, bool EXACT>   // EXACT: the logits feed a top-k (bit-exact sequential d-chain); otherwise only a softmax
 __global__ __launch_bounds__(128, 2) void fine_level_dma_kernel(const FineArgs a) {
     constexpr int KMAX = 64 * NPASS, NS = 2 * NPASS;
     constexpr int E = KMAX / 16;          // elements per lane in the 16-lane-row softmax / top-k
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(128, 2) void fine_level_dma_kernel(const FineArgs a
         const float* qsp = qs + par * 128;
         const int* ptp = ptab + par * 32;
         f32x4 lg[NPASS];
-        f32x4 acc[2];
+        f32x4 acc[4];
         static_for<0, NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int isv = s / NPASS, p = s % NPASS;
@@ -195,12 +195,29 @@ __global__ __launch_bounds__(128, 2) void fine_level_dma_kernel(const FineArgs a
                 for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(bp + rd[u]);
                 lds_reads_done();   // one wait for the 16 reads (hipcc otherwise threads them through the dependent MFMA chain, a wait each)
                 f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (EXACT) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, c, 0, 0, 0);
+                    for (int u = 0; u < 8; ++u) {
+                        c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, c, 0, 0, 0);
+                    }
+                } else {
+                    // no index depends on these logits (finest level: no top-k): four interleaved partial d-chains instead of one
+                    // sequential chain -- a dependent v_mfma_f32_4x4x1 waits ~28 cycles for its accumulator
+                    f32x4 c4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        c4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, c4[0], 0, 0, 0);
+                        c4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, c4[1], 0, 0, 0);
+                        c4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, c4[2], 0, 0, 0);
+                        c4[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, c4[3], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) c[f] = (c4[0][f] + c4[1][f]) + (c4[2][f] + c4[3][f]);
                 }
 #pragma unroll
                 for (int f = 0; f < 4; ++f) lg[p][f] = a.temp * c[f];
@@ -276,26 +293,26 @@ __global__ __launch_bounds__(128, 2) void fine_level_dma_kernel(const FineArgs a
             } else {
                 // ---- message += A . V over this pass's rows, two rows per instruction
                 if constexpr (p == 0) {
-                    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 const float* vrow = reinterpret_cast<const float*>(bp) + lane;              // + 64 m : rows 2m | 2m+1
                 const float* prow = Ald + (64 * p + (lane >> 5)) * 4 + (lane & 3);          // + 8 m  : P[row][child lane%4]
 #pragma unroll
                 for (int m = 0; m < 32; ++m)
-                    acc[m & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(prow[8 * m], vrow[64 * m], acc[m & 1], 0, 0, 0);
+                    acc[m & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(prow[8 * m], vrow[64 * m], acc[m & 3], 0, 0, 0);
                 if constexpr (p == NPASS - 1) {
                     f32x4 tot;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float x = acc[0][c] + acc[1][c];
+                        const float x = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
                         const unsigned xi = __float_as_uint(x);
                         const auto sw = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);   // lanes l and l ^ 32
                         tot[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                     }
                     pend = tot; pend_acc = acc_cur; pend_b = b; pend_l00 = l00; have_pend = true;
                 } else {
-                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+                    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
                 }
             }
         });
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(128, 2) void fine_level_dma_kernel(const FineArgs a
     flush();
 }
 
-template <int NPASS>
+template <int NPASS, bool EXACT>
 static int launch_fine(const FineArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * 2 * (64 * NPASS * 4 + 2 * 128 + 2 * 32 + 2 * 2048);
     // persistent grid: exactly the workgroups that are resident at once
@@ -316,7 +333,7 @@ static int launch_fine(const FineArgs& a, hipStream_t s) {
         int dev = 0, ncu = 0, per_cu = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fine_level_dma_kernel<NPASS>, 128, lds);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fine_level_dma_kernel<NPASS, EXACT>, 128, lds);
         if (e != hipSuccess || ncu <= 0 || per_cu <= 0) return e != hipSuccess ? (int)e : CASMTR_ERR_UNSUPPORTED;
         resident = ncu * per_cu / 8 * 8;
     }
@@ -324,7 +341,7 @@ static int launch_fine(const FineArgs& a, hipStream_t s) {
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
     ProfScope ps(CASMTR_PROF_QTA_FINE, s);
-    hipLaunchKernelGGL((fine_level_dma_kernel<NPASS>), dim3((unsigned)blocks), dim3(128), lds, s, a);
+    hipLaunchKernelGGL((fine_level_dma_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -339,5 +356,6 @@ int casmtr_qta_fine_level_dma(const float* q, const float* key, const float* val
     a.q = q; a.key = key; a.value = value; a.pidx = prev_idx; a.acc_in = acc_in; a.message = message; a.acc_out = acc_out;
     a.topk_score = topk_score; a.topk_idx = topk_idx; a.temp = temp; a.w_level = w_level; a.topk = topk; a.B = B;
     a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.H = H; a.Kp = Kp; a.nquads = (h0 / 2) * (w0 / 2); a.dbg = g_debug_flags;
-    return K <= 64 ? launch_fine<1>(a, s) : launch_fine<2>(a, s);
+    if (topk > 0) return K <= 64 ? launch_fine<1, true>(a, s) : launch_fine<2, true>(a, s);
+    return K <= 64 ? launch_fine<1, false>(a, s) : launch_fine<2, false>(a, s);
 }
