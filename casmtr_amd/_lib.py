@@ -38,7 +38,7 @@ SIGNATURES = {
     "casmtr_window_match_pos_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P] + [_I] * 7 + [_P]),
     "casmtr_window_expand_idx": (_I, [_P, _P] + [_I] * 7 + [_P]),
     "casmtr_nms_select_fwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _I, _I, _F, _I, _P, _I, _P,
-                                   _P, _P, _P, _P, _P] + [_I] * 5 + [_P]),
+                                   _P, _P, _P, _P, _P] + [_I] * 5 + [_P, _P]),
     "casmtr_nms_select_ws_bytes": (_SZ, [_I] * 3),
     "casmtr_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "casmtr_token_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -94,7 +94,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if l.casmtr_abi_version() != 1:
+        if l.casmtr_abi_version() != 2:
             raise RuntimeError("libcasmtr_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -473,13 +473,12 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S);
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C);
-    static bool attr_set = false;
     const size_t gemm_lds = sizeof(float) * (4 * 32 * 65 + 2 * 2 * 128 * 3);  // >= the 2 x [128][33] operand tiles
-    if (!attr_set) {
+    // per-device attribute: set on every call (cheap), never cached in a process-wide flag
+    if (recip)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+    else
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
-        attr_set = true;
-    }
     {
         ProfScope ps(CASMTR_PROF_DS_GEMM, s);
         const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
@@ -825,7 +824,7 @@ __global__ __launch_bounds__(256) void nms_flag_kernel(const float* __restrict__
                                                        const float* __restrict__ pre1, int hp1, int wp1, float pt1,
                                                        int border_rm, const int32_t* __restrict__ valid_hw,
                                                        int double_check, unsigned char* __restrict__ keep, int B, int H0,
-                                                       int W0, int H1, int W1) {
+                                                       int W0, int H1, int W1, const unsigned char* __restrict__ extra_keep) {
     const int N = H0 * W0;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * N) return;
@@ -845,6 +844,7 @@ __global__ __launch_bounds__(256) void nms_flag_kernel(const float* __restrict__
         k = (bi == i);
     }
     if (!(me > test_thr)) k = false;
+    if (extra_keep && !extra_keep[t]) k = false;   // PostProcess methods other than None / maxpool_nms, post_config rt / rd
     if (pre0) {
         int sy = (int)floorf((float)y * ((float)hp0 / (float)H0)); sy = min(sy, hp0 - 1);
         int sx = (int)floorf((float)x * ((float)wp0 / (float)W0)); sx = min(sx, wp0 - 1);
@@ -877,7 +877,7 @@ extern "C" int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* ne
                                      float pre_thr0, const float* pre_conf1, int hp1, int wp1, float pre_thr1,
                                      int border_rm, const int32_t* valid_hw, int double_check, void* ws, int64_t* b_ids,
                                      int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches, int B, int H0,
-                                     int W0, int H1, int W1, casmtr_stream_t stream) {
+                                     int W0, int H1, int W1, const uint8_t* extra_keep, casmtr_stream_t stream) {
     if (B <= 0 || H0 <= 0 || W0 <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int total = B * H0 * W0;
@@ -886,7 +886,7 @@ extern "C" int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* ne
     ProfScope ps(CASMTR_PROF_NMS_SELECT, s);
     hipLaunchKernelGGL(nms_flag_kernel, dim3((total + 255) / 256), dim3(256), 0, s, next_conf01, next_idx01, next_idx10,
                        nms_window, test_thr, pre_conf0, hp0, wp0, pre_thr0, pre_conf1, hp1, wp1, pre_thr1, border_rm,
-                       valid_hw, double_check, keep, B, H0, W0, H1, W1);
+                       valid_hw, double_check, keep, B, H0, W0, H1, W1, extra_keep);
     CASMTR_CHECK_LAUNCH();
     return run_compaction(keep, next_idx01, next_conf01, blk, total, H0 * W0, 1, B, b_ids, i_ids, j_ids, mconf, n_matches, s);
 }

@@ -398,12 +398,11 @@ static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
     constexpr int BODY = 4 * H * (KMAX + 4) + H * (4 * KMAX + 4);
     const size_t lds = sizeof(float) * (CANDN + (BODY > 4096 ? BODY : 4096));
     const int Lq = (a.h0 / 2) * (a.w0 / 2);
-    static bool attr_set = false;  // one process per GPU: no cross-device state to worry about
-    if (!attr_set) {
+    // the attribute is per device: set on every call (a host-side table write) so that a process driving several GPUs, or
+    // calling from several threads, never launches the 74 KB instantiations against the 64 KB default
+    if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quad_attn_kernel<H, KMAX, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     ProfScope ps(MODE == 0 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_CASCADE_ATTN, s);
     hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq * B), dim3(256), lds, s, a);
     CASMTR_CHECK_LAUNCH();

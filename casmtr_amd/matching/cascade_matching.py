@@ -34,7 +34,10 @@ class CascadeMatching(nn.Module):
         self.rt = cas_config["post_config"].get("rt", None)
         self.rd = cas_config["post_config"].get("rd", None)
         if self.rt is not None or self.rd is not None:
-            raise NotImplementedError("post_config rt/rd filters are not used by any shipped config")
+            # dead code in the reference: both filters read stage['next_conf_c01_s'] / ['next_idx_c01_s'] (:195,209,217), which
+            # CoarseMatching and CascadeMatching.forward always set to None (coarse_matching.py:74, cascade_matching.py:130), so
+            # the reference raises TypeError at the first `None / tensor`.  There is no behaviour to reproduce.
+            raise NotImplementedError("post_config rt / rd cannot run in the reference either (next_conf_c01_s is always None)")
         self.stage = stage
         self.next_topk = cas_config.get("next_topk", None)
         self.match_type = config["match_type"]
@@ -114,9 +117,10 @@ class CascadeMatching(nn.Module):
         valid = None
         if f"mask_{level}0" in data:
             valid = valid_extents(data[f"mask_{level}0"], data[f"mask_{level}1"])
+        extra = self.post_process.extra_mask(next_conf_c01, hw0)
         sel = ops.nms_select(next_conf_c01, next_idx_c01, next_idx_c10, hw0, hw1, nms_window=self.post_process.nms_window,
                              test_thr=float(self.test_thr), pre=pre, border_rm=int(self.border_rm), valid_hw=valid,
-                             double_check=bool(self.double_check))
+                             double_check=bool(self.double_check), extra_keep=extra)
         if self.defer_sync:
             return {"_pending": (sel, hw0, hw1)}
         # host sync, as `mask.sum() == 0` / torch.where in the reference (:254-258)

@@ -351,10 +351,11 @@ def window_match(feat_q, feat_k, idx, temperature=1.0, mask_q=None, mask_k=None,
 
 
 def nms_select(next_conf01, next_idx01, next_idx10, hw0, hw1, nms_window=5, test_thr=0.2, pre=(), border_rm=0,
-               valid_hw=None, double_check=True):
+               valid_hw=None, double_check=True, extra_keep=None):
     """pre: sequence of (pre_conf [B,hp*wp], (hp,wp), pre_thr), at most 2.  Returns dict with device count `n`."""
     _chk(next_conf01, "next_conf01"), _chk(next_idx01, "next_idx01", torch.int64), _chk(next_idx10, "next_idx10", torch.int64)
     _chk(valid_hw, "valid_hw", torch.int32)
+    extra_keep = _u8(extra_keep)
     B, N = next_conf01.shape
     dev = next_conf01.device
     pre = list(pre)
@@ -373,6 +374,7 @@ def nms_select(next_conf01, next_idx01, next_idx10, hw0, hw1, nms_window=5, test
                                            float(test_thr), _ptr(pre[0][0]), pre[0][1][0], pre[0][1][1], float(pre[0][2]),
                                            _ptr(pre[1][0]), pre[1][1][0], pre[1][1][1], float(pre[1][2]), int(border_rm),
                                            _ptr(valid_hw), int(bool(double_check)), _ptr(ws), _ptr(bi), _ptr(ii), _ptr(ji),
-                                           _ptr(mc), _ptr(n), B, hw0[0], hw0[1], hw1[0], hw1[1], _stream()),
+                                           _ptr(mc), _ptr(n), B, hw0[0], hw0[1], hw1[0], hw1[1], _ptr(extra_keep),
+                                           _stream()),
                    "nms_select_fwd")
     return dict(b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n, keep_ws=ws)

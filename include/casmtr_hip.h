@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 1
+#define CASMTR_ABI_VERSION 2
 int casmtr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -140,13 +140,15 @@ int casmtr_window_expand_idx(const int64_t* topk_pos, int64_t* up_idx, int B, in
  * PostProcess.apply for method None / 'maxpool_nms' (post_processing.py:41-44,111-121) and
  * mask_window_border[_with_padding] (cascade_functions.py:120-172).
  *   nms_window 0 = no NMS; pre_conf{0,1} nullable [B,hp*wp]; ws: casmtr_nms_select_ws_bytes(...) bytes scratch;
+ *   extra_keep nullable [B,H0*W0] uint8: a further per-token keep mask AND-ed in where PostProcess.apply's mask is formed
+ *   (post methods other than None / 'maxpool_nms', post_processing.py:76-110, and the rt / rd filters, cascade_matching.py:193-226);
  *   outputs in (b,i) order with capacity B*H0*W0, count in *n_matches (device).                                 */
 int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* next_idx01, const int64_t* next_idx10,
                           int nms_window, float test_thr, const float* pre_conf0, int hp0, int wp0, float pre_thr0,
                           const float* pre_conf1, int hp1, int wp1, float pre_thr1, int border_rm,
                           const int32_t* valid_hw, int double_check, void* ws, int64_t* b_ids,
                           int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches,
-                          int B, int H0, int W0, int H1, int W1, casmtr_stream_t stream);
+                          int B, int H0, int W0, int H1, int W1, const uint8_t* extra_keep, casmtr_stream_t stream);
 size_t casmtr_nms_select_ws_bytes(int B, int H0, int W0);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -228,8 +228,22 @@ def window_match(feat_q, feat_k, idx, temperature=1.0, mask_q=None, mask_k=None,
     return dict(conf_matrix=conf, next_conf=nc, next_idx=ni)
 
 
+def local_window_topk_mask(conf, hw, window_size, topk):
+    """PostProcess 'local_window_nms' (post_processing.py:76-93): the top-`topk` confidences of every non-overlapping
+    window_size x window_size tile survive.  (value desc, position asc); conf [B,h*w] -> bool [B,h*w]."""
+    conf = _f(conf)
+    B = conf.shape[0]
+    h, w = hw
+    ws = window_size
+    t = conf.reshape(B, h // ws, ws, w // ws, ws).transpose(0, 1, 3, 2, 4).reshape(B, -1, ws * ws)
+    order = np.argsort(-t, axis=2, kind="stable")[:, :, :topk]
+    keep = np.zeros_like(t, dtype=bool)
+    np.put_along_axis(keep, order, True, axis=2)
+    return np.ascontiguousarray(keep.reshape(B, h // ws, w // ws, ws, ws).transpose(0, 1, 3, 2, 4).reshape(B, h * w))
+
+
 def nms_select(next_conf01, next_idx01, next_idx10, hw0, hw1, nms_window=5, test_thr=0.2, pre=(), border_rm=0,
-               valid_hw=None, double_check=True):
+               valid_hw=None, double_check=True, extra_keep=None):
     """pre: sequence of (pre_conf [B,hp*wp], (hp,wp), pre_thr)."""
     next_conf01, next_idx01, next_idx10 = _f(next_conf01), _i(next_idx01), _i(next_idx10)
     B, N = next_conf01.shape
@@ -244,7 +258,7 @@ def nms_select(next_conf01, next_idx01, next_idx10, hw0, hw1, nms_window=5, test
                              C.c_int(n_pre), _p(pc0), *_ci(*pre[0][1]), C.c_float(pre[0][2]),
                              _p(pc1), *_ci(*pre[1][1]), C.c_float(pre[1][2]), C.c_int(border_rm), _p(vh),
                              C.c_int(int(double_check)), _p(keep), _p(bi), _p(ii), _p(ji), _p(mc),
-                             *_ci(B, hw0[0], hw0[1], hw1[0], hw1[1]))
+                             *_ci(B, hw0[0], hw0[1], hw1[0], hw1[1]), _p(_u8(extra_keep)))
     return dict(keep=keep.astype(bool), b_ids=bi[:n].copy(), i_ids=ii[:n].copy(), j_ids=ji[:n].copy(), mconf=mc[:n].copy())
 
 

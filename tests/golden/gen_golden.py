@@ -320,6 +320,7 @@ def gen_cascade_matching():
                 "border_rm": cfg.get("border_rm", 2), "double_check": cfg.get("double_check", True),
                 "train_pad_num_gt_min": 200, "match_type": "softmax", "dsmax_temperature": 1.0}
         post = {"method": "maxpool_nms", "window_size": 5} if cfg.get("nms", True) else {"method": None}
+        post = cfg.get("post", post)
         cas = {"propagation": "window", "dilated": 1, "post_config": post}
         cmod = CascadeMatching(mcfg, cas, stage="4c").eval()
         data = {"hw0_i": (h * 4, w * 4), "hw1_i": (h * 4, w * 4), "hw0_8c": (hc, wc), "hw1_8c": (hc, wc),

@@ -48,6 +48,9 @@ CASES = {
         "nms": dict(seed=51, B=2, coarse_hw=(12, 12), C=128, nms=True),
         "nonms_masks": dict(seed=52, B=2, coarse_hw=(12, 16), C=128, nms=False, masks=True, test_thr=0.1),
         "nms_nodc": dict(seed=53, B=1, coarse_hw=(10, 10), C=128, nms=True, double_check=False, border_rm=0),
+        # §8 f.4: PostProcess 'local_window_nms' (top-k per non-overlapping window), unused by the shipped configs
+        "local_window": dict(seed=54, B=2, coarse_hw=(12, 16), C=128, post=dict(method="local_window_nms", window_size=4, topk=2),
+                             test_thr=0.05),
     },
 }
 

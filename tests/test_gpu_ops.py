@@ -223,10 +223,13 @@ def test_window_match_and_select(ops, name, recip):
     assert np.array_equal(N(dg["next_idx"]), og["next_idx"])
     assert_close(N(dg["conf_matrix"]), og["conf_matrix"], SOFTMAX_TOL, "generic conf")
     # selection: fed with the reference's own stage outputs it is pure comparison logic -> exact vs the fixture
+    post, extra = cfg.get("post"), None
+    if post:   # 'local_window_nms': the survivors arrive as an extra keep mask (here: the oracle's restatement of post_processing.py:76-93)
+        extra = T(oracle.local_window_topk_mask(g["next_conf_c01"], (h, w), post["window_size"], post["topk"]).astype(np.uint8))
     sel = ops.nms_select(T(g["next_conf_c01"]), T(g["next_idx_c01"].astype(np.int64)), T(g["next_idx_c10"].astype(np.int64)),
-                         (h, w), (h, w), nms_window=5 if cfg.get("nms", True) else 0, test_thr=cfg.get("test_thr", 0.2),
+                         (h, w), (h, w), nms_window=5 if (cfg.get("nms", True) and not post) else 0, test_thr=cfg.get("test_thr", 0.2),
                          pre=[(T(inp["pre_conf"]), (hc, wc), cfg.get("pre_thr", 0.2))], border_rm=cfg.get("border_rm", 2),
-                         valid_hw=None if valid is None else T(valid), double_check=cfg.get("double_check", True))
+                         valid_hw=None if valid is None else T(valid), double_check=cfg.get("double_check", True), extra_keep=extra)
     n = int(sel["n"].item())
     assert n == len(g["b_ids"])
     assert np.array_equal(N(sel["b_ids"][:n]), g["b_ids"].astype(np.int64))

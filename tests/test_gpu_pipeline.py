@@ -109,6 +109,7 @@ def test_cascade_matching_module(name):
             "border_rm": cfg.get("border_rm", 2), "double_check": cfg.get("double_check", True),
             "train_pad_num_gt_min": 200, "match_type": "softmax", "dsmax_temperature": 1.0}
     post = {"method": "maxpool_nms", "window_size": 5} if cfg.get("nms", True) else {"method": None}
+    post = cfg.get("post", post)   # 'local_window_nms' (§8 f.4)
     cm = CascadeMatching(mcfg, {"propagation": "window", "dilated": 1, "post_config": post}, stage="4c", div_mode="cpu").eval()
     data = {"hw0_i": (h * 4, w * 4), "hw1_i": (h * 4, w * 4), "hw0_8c": (hc, wc), "hw1_8c": (hc, wc), "hw0_4c": (h, w),
             "hw1_4c": (h, w), "stage_8c": {"next_conf_c01": T(inp["pre_conf"])}}

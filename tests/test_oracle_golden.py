@@ -205,8 +205,11 @@ def test_cascade_matching(name):
     # the reference takes argmax of softmax VALUES (ties -> first), the oracle argmax of logits: equal, or an audited near tie
     audit_index_mismatches(d01["next_idx"], g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], mq, mk), "cascade next_idx_c01")
     audit_index_mismatches(d10["next_idx"], g["next_idx_c10"], dot_score_fn(inp["feat1"], inp["feat0"], mk, mq), "cascade next_idx_c10")
+    post, extra = cfg.get("post"), None
+    if post:   # PostProcess 'local_window_nms' (post_processing.py:76-93), restated in oracle.local_window_topk_mask
+        extra = oracle.local_window_topk_mask(g["next_conf_c01"], (h, w), post["window_size"], post["topk"])
     sel = oracle.nms_select(g["next_conf_c01"], g["next_idx_c01"].astype(np.int64), g["next_idx_c10"].astype(np.int64),
-                            (h, w), (h, w), nms_window=5 if cfg.get("nms", True) else 0,
+                            (h, w), (h, w), nms_window=5 if (cfg.get("nms", True) and not post) else 0, extra_keep=extra,
                             test_thr=cfg.get("test_thr", 0.2), pre=[(inp["pre_conf"], (hc, wc), cfg.get("pre_thr", 0.2))],
                             border_rm=cfg.get("border_rm", 2), valid_hw=valid, double_check=cfg.get("double_check", True))
     # fed with the reference's own stage outputs the selection is pure integer / comparison logic: exact
