@@ -48,7 +48,7 @@ SIGNATURES = {
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
 }
-PROF_COUNT = 15
+PROF_COUNT = 16
 
 
 def prof_enable(on: bool):

@@ -143,6 +143,28 @@ __device__ __forceinline__ void glds_wait() {
 // every LDS read issued so far has returned (before a DMA may overwrite the buffer they read)
 __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// v of lane (l ^ J) for a compile-time J in {1, 2, 4, 8, 16, 32}, on the VALU (DPP quad permutes / row shifts / row rotation,
+// gfx950 row and half swaps) instead of __shfl_xor's ds_bpermute: a 64-lane bitonic sort is 21 DEPENDENT exchange steps, and each
+// ds_bpermute round trip costs ~70 cycles of LDS latency on that chain.
+template <int J>
+__device__ __forceinline__ unsigned wave_xor_u32(unsigned v) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "power of two below the wave size");
+    if constexpr (J == 1) return dpp_u32<0xB1>(v);         // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return dpp_u32<0x4E>(v);    // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {
+        // banks = the four quads of a 16-lane row: quads 0, 2 read 4 lanes up (row_shl:4), quads 1, 3 read 4 lanes down (row_shr:4)
+        const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+    } else if constexpr (J == 8) return dpp_u32<0x128>(v);  // row_ror:8
+    else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = halves [lo,lo], r[1] = [hi,hi]
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E).  `#pragma unroll` leaves long stage loops rolled
 // (then every per-stage constant -- buffer parity, vmcnt immediates, register-array indices -- becomes a runtime value)
 template <int B, int E, typename F>

@@ -524,9 +524,11 @@ __global__ __launch_bounds__(256) void coarse_logits_kernel(const float* __restr
     }
 }
 
-// (2) one wave per (b,h,l) row: softmax over S (probabilities written back in place), top-k by iterative wave argmax.
+// (2) one wave per (b,h,l) row: softmax statistics (max, sum) and top-k.  The probabilities themselves are NOT written back: the
+//     A.V kernel recomputes exp(x - max) / sum from the logits (fast exp, reciprocal multiply: the message carries a 1e-4
+//     tolerance and no index depends on it), which makes this pass a pure read of the [B,H,L,S_pad] workspace (122 MB less HBM / Infinity Cache traffic per call at 26x26, B = 8).
 template <int EMAX>
-__global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg, float* __restrict__ topk_score,
+__global__ __launch_bounds__(256) void coarse_row_kernel(const float* __restrict__ Sg, float* __restrict__ rowstat, float* __restrict__ topk_score,
                                                          int64_t* __restrict__ topk_idx, int topk, int B, int L, int S,
                                                          int Spad, int H) {
     const int lane = threadIdx.x & 63;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg,
     const int rowid = blockIdx.x * 4 + wave;
     if (rowid >= B * H * L) return;
     const int bh = rowid / L, l = rowid % L, b = bh / H, h = bh % H;
-    float* row = Sg + (size_t)rowid * Spad;
+    const float* row = Sg + (size_t)rowid * Spad;
     float lv[EMAX];
     unsigned key[EMAX];
     unsigned lm = 0;
@@ -555,10 +557,8 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg,
     }
     s = wave_sum_f32(s);
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-        ps[e] = ps[e] / s;
-        if (e * 64 + lane < Spad) row[e * 64 + lane] = ps[e];  // zero in the [S,Spad) padding
-    }
+    for (int e = 0; e < EMAX; ++e) ps[e] = ps[e] / s;
+    if (lane == 0) { rowstat[2 * (size_t)rowid] = m; rowstat[2 * (size_t)rowid + 1] = s; }
     // ---- top-k, fast path.  (logit desc, position asc) is a total order, so the answer is the sorted prefix of ANY superset of
     // the k best.  theta := the k-th largest of the 64 per-lane maxima (a 64-lane bitonic sort of keys): at least k elements
     // are >= theta, and for rows that are not pathologically concentrated in a few lanes at most 64 are.  Those are compacted
@@ -572,14 +572,15 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg,
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) cur = max(cur, key[e]);
         unsigned srt = cur;
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const unsigned o = (unsigned)__shfl_xor((int)srt, j);
-                const bool keep_max = ((lane & k) == 0) == ((lane & j) == 0);   // descending overall
+        static_for<1, 7>([&](auto kq_) {   // 64-lane bitonic sort, descending: 21 compare-exchange steps
+            constexpr int kq = 1 << decltype(kq_)::value;
+            static_for<0, decltype(kq_)::value>([&](auto j_) {
+                constexpr int j = kq >> (1 + decltype(j_)::value);
+                const unsigned o = wave_xor_u32<j>(srt);
+                const bool keep_max = ((lane & kq) == 0) == ((lane & j) == 0);
                 srt = keep_max ? max(srt, o) : min(srt, o);
-            }
+            });
+        });
         const unsigned theta = (unsigned)__builtin_amdgcn_readlane((int)srt, topk - 1);
         int cnt = 0;
         if (theta != 0u) {
@@ -606,18 +607,19 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             unsigned sk = lane < cnt ? ck[lane] : 0u;
             unsigned sp = lane < cnt ? cp[lane] : 0xFFFFFFFFu;
-#pragma unroll
-            for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const unsigned ok = (unsigned)__shfl_xor((int)sk, j);
-                    const unsigned op = (unsigned)__shfl_xor((int)sp, j);
+            static_for<1, 7>([&](auto kq_) {   // bitonic sort on (key desc, position asc)
+                constexpr int kq = 1 << decltype(kq_)::value;
+                static_for<0, decltype(kq_)::value>([&](auto j_) {
+                    constexpr int j = kq >> (1 + decltype(j_)::value);
+                    const unsigned ok = wave_xor_u32<j>(sk);
+                    const unsigned op = wave_xor_u32<j>(sp);
                     const bool other_first = ok > sk || (ok == sk && op < sp);   // does the partner precede me in the order?
-                    const bool want_first = ((lane & k) == 0) == ((lane & j) == 0);
+                    const bool want_first = ((lane & kq) == 0) == ((lane & j) == 0);
                     const bool take = want_first == other_first;
                     sk = take ? ok : sk;
                     sp = take ? op : sp;
-                }
+                });
+            });
             if (lane < topk) {
                 const size_t o = (((size_t)b * L + l) * topk + lane) * H + h;
                 topk_idx[o] = sp;
@@ -652,9 +654,9 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(float* __restrict__ Sg,
 }
 
 // (3) message[b,l,h,:] = sum_s P[bh][l][s] * v[b,s,h,:] on the fp32 matrix cores (s ascending chain).
-__global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict__ Pg, const float* __restrict__ v,
-                                                        float* __restrict__ message, float* __restrict__ acc_out,
-                                                        float w_level, int L, int S, int Spad, int H) {
+__global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict__ Pg, const float* __restrict__ rowstat,
+                                                        const float* __restrict__ v, float* __restrict__ message,
+                                                        float* __restrict__ acc_out, float w_level, int L, int S, int Spad, int H) {
     __shared__ float Ps[128][33];
     __shared__ float Vs[32][33];
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -668,7 +670,9 @@ __global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict_
     // 1.5 workgroups per CU nothing else covered the load latency)
     const int prow = tid >> 1, pc0 = (tid & 1) * 16, pl = l0 + prow;
     const int vr = tid >> 3, vc = (tid & 7) * 4;
-    const float* pbase = Pg + ((size_t)bh * L + (pl < L ? pl : L - 1)) * Spad + pc0;
+    const size_t prow_id = (size_t)bh * L + (pl < L ? pl : L - 1);
+    const float* pbase = Pg + prow_id * Spad + pc0;   // logits; probability = exp(x - max) / sum
+    const float rmax = rowstat[2 * prow_id], rinv = 1.0f / rowstat[2 * prow_id + 1];
     f32x4 pp[4], vv;
     auto fetch = [&](int s0) {
 #pragma unroll
@@ -681,9 +685,11 @@ __global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict_
         __syncthreads();   // previous chunk fully consumed
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 p = pl < L ? pp[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            Ps[prow][pc0 + 4 * i + 0] = p.x; Ps[prow][pc0 + 4 * i + 1] = p.y;
-            Ps[prow][pc0 + 4 * i + 2] = p.z; Ps[prow][pc0 + 4 * i + 3] = p.w;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {   // zero beyond the last key (the logits workspace holds temp * 0 there) and beyond the last row
+                const int sc = s0 + pc0 + 4 * i + c;
+                Ps[prow][pc0 + 4 * i + c] = (pl < L && sc < S) ? __expf(pp[i][c] - rmax) * rinv : 0.f;   // message: 1e-4 tolerance, no index depends on it
+            }
         }
         Vs[vr][vc + 0] = vv.x; Vs[vr][vc + 1] = vv.y; Vs[vr][vc + 2] = vv.z; Vs[vr][vc + 3] = vv.w;
         if (s0 + 32 < Spad) fetch(s0 + 32);
@@ -707,9 +713,23 @@ __global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict_
     }
 }
 
+// coarse_fused.hip
+int casmtr_qta_coarse_level_fused(const float* q, const float* k, const float* v, float temp, int topk, float w_level, float* message,
+                                  float* acc_out, float* topk_score, int64_t* topk_idx, int B, int L, int S, int H, hipStream_t s);
+
+// default: the three-kernel path below; CASMTR_COARSE_KERNEL=fused selects the single-kernel path (coarse_fused.hip, S <= 1024).
+// Measured at 26x26, H = 8, B = 8: 153 us per call against 206 us fused -- the [B,H,L,S_pad] workspace (122 MB) stays in the
+// 256 MB Infinity Cache between the three kernels, so its four passes are cheap, while the fused kernel at 3 workgroups per CU
+// exposes the latency of its operand loads; the row phase (softmax + top-32) costs the same ~57 us in both.  Read per call.
+static bool coarse_use_fused(int S) {
+    const char* ev = getenv("CASMTR_COARSE_KERNEL");
+    return ev && !strcmp(ev, "fused") && S <= 1024;
+}
+
 extern "C" size_t casmtr_qta_coarse_level_ws_floats(int B, int L, int S, int H) {
+    if (coarse_use_fused(S)) return 1;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;
-    return (size_t)B * H * L * Spad;
+    return (size_t)B * H * L * Spad + 2 * (size_t)B * H * L;   // logits + per-row (max, sum)
 }
 
 extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const float* v, float temp, int topk,
@@ -719,6 +739,10 @@ extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const
     if (D != 32 || topk > S) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (coarse_use_fused(S)) {
+        const int r = casmtr_qta_coarse_level_fused(q, k, v, temp, topk, w_level, message, acc_out, topk_score, topk_idx, B, L, S, H, s);
+        if (r != CASMTR_ERR_UNSUPPORTED) return r;
+    }
     const int Spad = (S + 63) / 64 * 64;
     {
         ProfScope ps(CASMTR_PROF_COARSE_LOGITS, s);
@@ -727,26 +751,27 @@ extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const
     }
     CASMTR_CHECK_LAUNCH();
     const int rows = B * H * L;
+    float* rowstat = logits_ws + (size_t)rows * Spad;
     const dim3 rg((rows + 3) / 4);
     const int E = Spad / 64;
     prof_begin(CASMTR_PROF_COARSE_ROW, s);
     if (E <= 4)
-        hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else if (E <= 8)
-        hipLaunchKernelGGL(coarse_row_kernel<8>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<8>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else if (E <= 12)
-        hipLaunchKernelGGL(coarse_row_kernel<12>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<12>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else if (E <= 16)
-        hipLaunchKernelGGL(coarse_row_kernel<16>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<16>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else if (E <= 32)
-        hipLaunchKernelGGL(coarse_row_kernel<32>, rg, dim3(256), 0, s, logits_ws, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<32>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
     else
         return CASMTR_ERR_UNSUPPORTED;
     prof_end(CASMTR_PROF_COARSE_ROW, s);
     CASMTR_CHECK_LAUNCH();
     {
         ProfScope ps(CASMTR_PROF_COARSE_AV, s);
-        hipLaunchKernelGGL(coarse_av_kernel, dim3((L + 127) / 128, B * H), dim3(256), 0, s, logits_ws, v, message, acc_out,
+        hipLaunchKernelGGL(coarse_av_kernel, dim3((L + 127) / 128, B * H), dim3(256), 0, s, logits_ws, rowstat, v, message, acc_out,
                            w_level, L, S, Spad, H);
     }
     CASMTR_CHECK_LAUNCH();

@@ -70,7 +70,9 @@ int casmtr_nchw_to_tokens_multi(const float* const* src, float* const* dst, cons
 
 /* QTAttB.process_coarse_level (modules/quadtree_attention.py:161-178): dense QK^T (fp32 MFMA) -> softmax over S
  * -> top-k -> A.V.   q [B,L,H,D], k/v [B,S,H,D].
- *   logits_ws : workspace [B,H,L,S_pad] floats, S_pad = round_up(S,64)  (also receives A if want_A, same layout)
+ *   logits_ws : workspace of casmtr_qta_coarse_level_ws_floats(B,L,S,H) floats ([B,H,L,S_pad] logits, S_pad = round_up(S,64),
+ *               + [B,H,L,2] row maxima / sums) for the three-kernel path (default); the fused single-kernel path (CASMTR_COARSE_KERNEL=fused, S <= 1024) keeps the tile
+ *               in LDS and needs none (ws_floats then returns 1)
  *   message [B,L,H,D]; acc_out [B,L,H,D] = message * w_level (NULL to skip); topk_score/topk_idx [B,L,topk,H]  */
 int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const float* v, float temp, int topk, float w_level,
                                 float* logits_ws, float* message, float* acc_out, float* topk_score,
@@ -179,7 +181,7 @@ enum {
     CASMTR_PROF_DS_GEMM = 0, CASMTR_PROF_DS_REDUCE, CASMTR_PROF_DS_CONF, CASMTR_PROF_DS_SELECT,
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
-    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COUNT
+    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
 /* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).

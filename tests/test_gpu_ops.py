@@ -341,10 +341,12 @@ def test_empty_batch_and_limits(ops):
         ops.window_match(z(1, 16, 64), z(1, 400, 64), torch.zeros((1, 16, 144), device=DEV, dtype=torch.int64))
 
 
+@pytest.mark.parametrize("kernel", ["fused", "split"])
 @pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid"])
-def test_coarse_topk_paths(ops, kind):
+def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
     """coarse-level top-k: the bitonic fast path (<= 64 survivors of the lane-maxima threshold) and the iterative fallback
     (ties / concentrated rows) must both return the oracle's list, ordered (logit desc, position asc)"""
+    monkeypatch.setenv("CASMTR_COARSE_KERNEL", kernel)   # single fused kernel | default logits / row / A.V kernels
     r = np.random.default_rng({"random": 1, "all_equal": 2, "one_lane_heavy": 3, "many_ties": 4, "few_valid": 5}[kind])
     B, H, L, S, topk = 1, 2, 40, 676, 32
     if kind == "few_valid":
@@ -364,6 +366,8 @@ def test_coarse_topk_paths(ops, kind):
     out = ops.qta_coarse_level(T(q.reshape(B, L, C)), T(k.reshape(B, S, C)), T(v.reshape(B, S, C)), H, topk, w_level=1.0)
     assert np.array_equal(N(out["topk_idx"]), o[2]), kind
     assert_close(N(out["topk_score"]), o[1], SOFTMAX_TOL, "topk_score")
+    assert_close(N(out["message"]), o[0], SOFTMAX_TOL, "message")
+    assert_close(N(out["acc"]), o[0], SOFTMAX_TOL, "message * weight")
 
 
 @pytest.mark.parametrize("kernel", ["quad", "dma"])

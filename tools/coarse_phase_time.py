@@ -1,0 +1,34 @@
+"""Times the coarsest QTAttB level (26x26, H=8, top-32, B=8) for the fused and the three-kernel path; casmtr_debug_set bits on the
+fused kernel: 1 = stop after the logits phase, 2 = skip the row phase, 4 = stop before A.V."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from casmtr_amd import _lib, ops
+
+B, H, C, L = 8, 8, 256, 676
+g = torch.Generator(device="cuda").manual_seed(0)
+q, k, v = (torch.randn(B, L, C, generator=g, device="cuda") for _ in range(3))
+
+
+def t(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for kern, flagset in (("split", (0,)), ("fused", (0, 1, 2, 4, 6))):
+    os.environ["CASMTR_COARSE_KERNEL"] = kern
+    for flags in flagset:
+        _lib.lib().casmtr_debug_set(flags)
+        print(f"[{kern}] debug flags {flags}: {t(lambda: ops.qta_coarse_level(q, k, v, H, 32, w_level=0.3, want_message=False)):7.1f} us")
+_lib.lib().casmtr_debug_set(0)
