@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""SURVEY.md §8 f.3 fixture: the reference's whole CasMTR-4c (outdoor stage-3 config, test_single_pair.py's --NMS post-processing)
+on the london_bridge demo pair at 256x192, CPU, with the deterministic weights of tests/golden_inputs.model_state().
+
+The model is evaluated stage by stage by calling the reference's own sub-modules; at the two boundaries that feed discrete
+decisions (the 1/8 features entering the QuadTree transformer, the 1/8 and 1/4 tokens entering the matchers) the tensors are
+rounded to fp16-exact values first, so the fixture stores them compactly AND both implementations see bit-identical inputs there.
+Stored: the two resized images (uint8), strided samples of the backbone maps, the rounded stage inputs / outputs, the matchers'
+index outputs and the final sub-pixel matches.
+
+    python tests/golden/gen_golden_model.py            (build container only; needs /root/reference)
+
+Nothing of the reference is copied: modules are imported and called, only numbers are stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import gen_golden as gg  # noqa: E402  installs the extension / kornia / timm stubs
+import ref_stubs  # noqa: E402
+import gen_golden_e2e as ge  # noqa: E402
+from golden_inputs import model_state  # noqa: E402
+
+REF = gg.REF
+THRESHOLDS = dict(coarse_thr=0.002, cascade_thr=0.011, pre_thr=0.0, double_check=False)   # a random-weight network is not confident: test thresholds
+
+
+def h16(t):
+    return t.detach().half().float()
+
+
+def build_reference():
+    ref_stubs.install_full_model_extras()
+    from configs.default import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(REF, "configs/model_configs/outdoor/loftr_ds_quadtree_cas_twins_large_stage3.py"))
+    mc = ref_stubs.lower(cfg)["loftr"]
+    mc["coarse2"]["post_config"]["method"] = "maxpool_nms"
+    mc["coarse2"]["post_config"]["window_size"] = 5
+    mc["match_coarse"]["thr"] = THRESHOLDS["coarse_thr"]
+    mc["match_cascade"]["test_thr"] = [THRESHOLDS["cascade_thr"]]
+    mc["match_cascade"]["pre_thr"] = [[THRESHOLDS["pre_thr"]]]
+    mc["match_cascade"]["double_check"] = [THRESHOLDS["double_check"]]
+    from src.model.cascade_model_stage3 import CasMTR
+    model = CasMTR(config=mc).eval()
+    sd = model.state_dict()
+    new = model_state({k: tuple(v.shape) for k, v in sd.items()})
+    for k, v in new.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    import json
+    with open(os.path.join(HERE, "model_state_keys.json"), "w") as f:   # names + shapes of the reference's checkpoint layout
+        json.dump({k: list(v.shape) for k, v in sd.items()}, f, indent=0)
+    return model
+
+
+def main():
+    model = build_reference()
+    im0, im1 = ge.load_pair()
+    u8 = [(x * 255.0).round().to(torch.uint8) for x in (im0, im1)]
+    im0, im1 = [x.float() / 255.0 for x in u8]
+    data = {"image0": im0, "image1": im1, "bs": 1, "hw0_i": im0.shape[2:], "hw1_i": im1.shape[2:]}
+    out = {"image0": u8[0], "image1": u8[1]}
+    with torch.no_grad():
+        f8, f4, ff = model.backbone(torch.cat([im0, im1], 0))
+        data.update({"hw0_8c": f8.shape[2:], "hw1_8c": f8.shape[2:], "hw0_4c": f4.shape[2:], "hw1_4c": f4.shape[2:],
+                     "hw0_f": ff.shape[2:], "hw1_f": ff.shape[2:]})
+        out.update(bb_f8_sub=f8[:, ::4, ::2, ::2].contiguous(), bb_f4_sub=f4[:, ::4, ::4, ::4].contiguous(),
+                   bb_ff_sub=ff[:, ::4, ::8, ::8].contiguous())
+        # ---- 1/8 stage on fp16-exact features
+        f8r = h16(f8)
+        out["f8"] = f8r.half()
+        t8_0, t8_1 = model.loftr_coarse_8c.forward(model.pos_encoding_8c(f8r[:1]), model.pos_encoding_8c(f8r[1:]), None, None)
+        t8_0, t8_1 = h16(t8_0), h16(t8_1)
+        out["t8"] = torch.cat([t8_0, t8_1]).half()
+        model.coarse_matching_8c.forward(t8_0, t8_1, data, mask_c0=None, mask_c1=None, level="8c")
+        s8 = data["stage_8c"]
+        out.update(m8_next_idx_c01=s8["next_idx_c01"].to(torch.int16), m8_next_idx_c10=s8["next_idx_c10"].to(torch.int16),
+                   m8_next_conf_c01=s8["next_conf_c01"], m8_i_ids=s8["i_ids"].to(torch.int16), m8_j_ids=s8["j_ids"].to(torch.int16),
+                   m8_mconf=s8["mconf"])
+        # ---- 1/4 stage: the reference's own (unrounded) 1/4 features + the rounded 1/8 tokens
+        g = lambda t: t.transpose(1, 2).reshape(1, -1, *f8.shape[2:])
+        f4_0, f4_1 = model.up_block1.forward(f4[:1], f4[1:], g(t8_0), g(t8_1), data["hw0_4c"], data["hw1_4c"], 1)
+        out["up_sub"] = torch.cat([f4_0, f4_1])[:, ::4, ::4, ::4].contiguous()
+        t4_0, t4_1, idx01, idx10, _ = model.loftr_coarse_4c.forward(model.pos_encoding_4c(f4_0), model.pos_encoding_4c(f4_1),
+                                                                    s8["next_idx_c01"], s8["next_idx_c10"], data=data)
+        t4_0, t4_1 = h16(t4_0), h16(t4_1)
+        out["t4"] = torch.cat([t4_0, t4_1]).half()
+        model.cascade_matching_4c.forward(t4_0, t4_1, idx01, idx10, data, mask_c0=None, mask_c1=None, heatmap_c0=None, level="4c",
+                                          pre_level="8c")
+        s4 = data["stage_4c"]
+        out.update(m4_b_ids=s4["b_ids"].to(torch.int16), m4_i_ids=s4["i_ids"].to(torch.int16), m4_j_ids=s4["j_ids"].to(torch.int16),
+                   m4_mconf=s4["mconf"], m4_mkpts0_c=s4["mkpts0_c"], m4_mkpts1_c=s4["mkpts1_c"])
+        # ---- fine stage on the reference's match list
+        w0, w1 = model.fine_preprocess.forward(ff[:1], ff[1:], t4_0, t4_1, data)
+        if w0.size(0):
+            w0, w1 = model.loftr_fine(w0, w1)
+        model.fine_matching.forward(w0.float(), w1.float(), data)
+        out.update(mkpts0_f=data["mkpts0_f"], mkpts1_f=data["mkpts1_f"], expec_f=data["expec_f"])
+    out["thresholds"] = np.array([THRESHOLDS["coarse_thr"], THRESHOLDS["cascade_thr"], THRESHOLDS["pre_thr"], float(THRESHOLDS["double_check"])],
+                                 dtype=np.float32)
+    arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
+    path = os.path.join(HERE, "model_london_bridge.npz")
+    np.savez_compressed(path, **arrs)
+    print(f"model_london_bridge: {os.path.getsize(path) / 1e6:.2f} MB; coarse matches {len(arrs['m8_i_ids'])}, "
+          f"cascade matches {len(arrs['m4_i_ids'])}; |t8| {float(t8_0.abs().mean()):.3f} |t4| {float(t4_0.abs().mean()):.3f} "
+          f"conf8 max {float(s8['next_conf_c01'].max()):.3f} mconf4 mean {float(s4['mconf'].mean()) if len(s4['mconf']) else -1:.3f} "
+          f"expec std {float(data['expec_f'][:, :2].std()) if len(data['expec_f']) else -1:.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -27,8 +27,11 @@ def install_third_party():
     kug = stub("kornia.utils.grid")
 
     def create_meshgrid(h, w, normalized_coordinates=True, device=None, dtype=torch.float32):
-        ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=dtype), torch.arange(w, device=device, dtype=dtype),
-                                indexing="ij")
+        if normalized_coordinates:   # kornia: linspace(-1, 1) along each axis
+            ys, xs = torch.linspace(-1, 1, h, device=device, dtype=dtype), torch.linspace(-1, 1, w, device=device, dtype=dtype)
+        else:
+            ys, xs = torch.arange(h, device=device, dtype=dtype), torch.arange(w, device=device, dtype=dtype)
+        ys, xs = torch.meshgrid(ys, xs, indexing="ij")
         return torch.stack([xs, ys], -1)[None]
 
     kug.create_meshgrid = create_meshgrid

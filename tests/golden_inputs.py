@@ -217,3 +217,33 @@ def checksum(inp):
         for v in vs:
             c = zlib.crc32(np.ascontiguousarray(v).tobytes(), c)
     return np.array([c], dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f.3 model harness: one deterministic state dict for the whole CasMTR-4c, rebuilt from the parameter names alone so that
+# the fixture generator (reference model, CPU) and the GPU test (casmtr_amd.model) hold identical weights without storing
+# 30 M floats.  Scales are chosen so that activations stay O(1) through the random network.
+def model_state(shapes):
+    """shapes: {state-dict key: shape} -> {key: float32 / int64 ndarray}.  Integer entries (num_batches_tracked, window) are
+    skipped: both sides keep their own, identical, constructor values."""
+    out = {}
+    for key, shape in shapes.items():
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked" or key.endswith(".window"):
+            continue
+        r = np.random.RandomState(zlib.crc32(key.encode()) & 0x7FFFFFFF)
+        shape = tuple(shape)
+        n = r.standard_normal(shape).astype(np.float32)
+        if leaf == "running_var":
+            v = 1.0 + 0.25 * np.abs(n)
+        elif leaf == "running_mean":
+            v = 0.05 * n
+        elif leaf == "bias":
+            v = 0.05 * n
+        elif len(shape) == 1:                       # LayerNorm / BatchNorm gains, QTAttB level weights
+            v = 1.0 + 0.1 * n
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = n * (1.0 / np.sqrt(fan_in))
+        out[key] = np.ascontiguousarray(v, dtype=np.float32)
+    return out

@@ -1,0 +1,195 @@
+"""casmtr_amd.model.CasMTR4c against the reference's CasMTR (cascade_model_stage3.py) evaluated on CPU by
+tests/golden/gen_golden_model.py -- same deterministic weights (golden_inputs.model_state), london_bridge pair at 256x192.
+
+CPU tests: checkpoint layout (every state-dict key / shape of the reference), the torch-only pieces (backbone, fine stage).
+GPU tests: every stage on the reference's stage inputs (bit-identical where the fixture stores them), then the whole forward."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_inputs import model_state
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = os.path.join(HERE, "golden", "model_london_bridge.npz")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    z = np.load(FIX)
+    return {k: z[k] for k in z.files}
+
+
+def _config(fx):
+    from casmtr_amd.model import outdoor_4c_config
+    c = outdoor_4c_config()
+    thr = fx["thresholds"]
+    c["match_coarse"]["thr"] = float(thr[0])
+    c["match_cascade"].update(test_thr=float(thr[1]), pre_thr=[float(thr[2])], double_check=bool(thr[3]))
+    return c
+
+
+def _model(fx, device):
+    from casmtr_amd.model import CasMTR4c
+    m = CasMTR4c(_config(fx)).eval()
+    sd = m.state_dict()
+    for k, v in model_state({k: tuple(v.shape) for k, v in sd.items()}).items():
+        sd[k] = torch.from_numpy(v)
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+def _images(fx, device):
+    return [torch.from_numpy(fx[k]).to(device).float() / 255.0 for k in ("image0", "image1")]
+
+
+def _close(a, b, tol, what, frac=1.0):
+    a, b = a.detach().float().cpu(), torch.as_tensor(np.asarray(b, dtype=np.float32))
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs() / (1.0 + b.abs())
+    ok = float((err <= tol).float().mean())
+    assert ok >= frac, f"{what}: {100 * ok:.3f}% within {tol} (max err {float(err.max()):.3e})"
+
+
+def test_state_dict_layout_matches_reference():
+    from casmtr_amd.model import CasMTR4c
+    with open(os.path.join(HERE, "golden", "model_state_keys.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v.shape) for k, v in CasMTR4c().state_dict().items()}
+    assert sorted(mine) == sorted(ref)
+    assert all(mine[k] == ref[k] for k in ref)
+    # 'matcher.'-prefixed checkpoints (the lightning wrapper's) load as well
+    m = CasMTR4c()
+    m.load_state_dict({"matcher." + k: v for k, v in m.state_dict().items()})
+
+
+def test_backbone_cpu(fx):
+    m = _model(fx, "cpu")
+    im0, im1 = _images(fx, "cpu")
+    with torch.no_grad():
+        f8, f4, ff = m.backbone(torch.cat([im0, im1], 0))
+    _close(f8[:, ::4, ::2, ::2], fx["bb_f8_sub"], 2e-4, "1/8 features")
+    _close(f4[:, ::4, ::4, ::4], fx["bb_f4_sub"], 2e-4, "1/4 features")
+    _close(ff[:, ::4, ::8, ::8], fx["bb_ff_sub"], 2e-4, "1/2 features")
+
+
+def _stage4_from_fixture(fx, device):
+    t = lambda k, dt=torch.int64: torch.from_numpy(fx[k]).to(device).to(dt)
+    return {"b_ids": t("m4_b_ids"), "i_ids": t("m4_i_ids"), "j_ids": t("m4_j_ids"), "m_bids": t("m4_b_ids"),
+            "mconf": t("m4_mconf", torch.float32), "mkpts0_c": t("m4_mkpts0_c", torch.float32), "mkpts1_c": t("m4_mkpts1_c", torch.float32)}
+
+
+def _fine_stage(fx, device):
+    m = _model(fx, device)
+    im0, im1 = _images(fx, device)
+    data = {"image0": im0, "image1": im1}
+    with torch.no_grad():
+        _, _, (ff0, ff1) = m.features(data)
+        t4 = torch.from_numpy(fx["t4"]).to(device).float()
+        data["stage_4c"] = _stage4_from_fixture(fx, device)
+        m.fine_stage(ff0, ff1, t4[:1], t4[1:], data)
+    assert len(fx["mkpts1_f"]) >= 50
+    _close(data["mkpts0_f"], fx["mkpts0_f"], 0, "mkpts0_f")
+    _close(data["expec_f"], fx["expec_f"], 1e-3, "expec_f")
+    assert float((data["mkpts1_f"].cpu() - torch.from_numpy(fx["mkpts1_f"])).abs().max()) < 5e-3   # pixels
+
+
+def test_fine_stage_cpu(fx):
+    _fine_stage(fx, "cpu")
+
+
+@pytest.mark.gpu
+def test_fine_stage_gpu(fx):
+    _fine_stage(fx, "cuda")
+
+
+@pytest.mark.gpu
+def test_backbone_gpu(fx):
+    m = _model(fx, "cuda")
+    im0, im1 = _images(fx, "cuda")
+    with torch.no_grad():
+        f8, f4, ff = m.backbone(torch.cat([im0, im1], 0))
+    _close(f8[:, ::4, ::2, ::2], fx["bb_f8_sub"], 1e-3, "1/8 features")
+    _close(f4[:, ::4, ::4, ::4], fx["bb_f4_sub"], 1e-3, "1/4 features")
+    _close(ff[:, ::4, ::8, ::8], fx["bb_ff_sub"], 1e-3, "1/2 features")
+
+
+def _sizes(fx, data):
+    H, W = fx["image0"].shape[2:]
+    data.update(bs=1, hw0_i=(H, W), hw1_i=(H, W), hw0_8c=(H // 8, W // 8), hw1_8c=(H // 8, W // 8), hw0_4c=(H // 4, W // 4),
+                hw1_4c=(H // 4, W // 4), hw0_f=(H // 2, W // 2), hw1_f=(H // 2, W // 2))
+    return data
+
+
+def _agree(a, b):
+    return float((torch.as_tensor(a).cpu().long() == torch.as_tensor(np.asarray(b)).long()).float().mean())
+
+
+@pytest.mark.gpu
+def test_coarse_stage_on_reference_features(fx):
+    """QuadTree transformer (6 layers, three-level top-k inside each) + dual-softmax matcher on the fixture's fp16-exact 1/8
+    features.  The transformer output is continuous except where a top-k near-tie flips, so a small fraction of tokens may
+    differ; the matcher then runs on the reference's own tokens and must reproduce its indices."""
+    m = _model(fx, "cuda")
+    f8 = torch.from_numpy(fx["f8"]).cuda().float()
+    data = _sizes(fx, {})
+    with torch.no_grad():
+        t0, t1 = m.coarse_stage(f8[:1], f8[1:], data)
+    _close(torch.cat([t0, t1]), fx["t8"].astype(np.float32), 3e-3, "1/8 tokens", frac=0.995)
+    # the matcher on the reference's tokens
+    t8 = torch.from_numpy(fx["t8"]).cuda().float()
+    data = _sizes(fx, {})
+    m.coarse_matching_8c(t8[:1].contiguous(), t8[1:].contiguous(), data, level="8c")
+    s8 = data["stage_8c"]
+    assert _agree(s8["next_idx_c01"], fx["m8_next_idx_c01"]) == 1.0
+    assert _agree(s8["next_idx_c10"], fx["m8_next_idx_c10"]) == 1.0
+    _close(s8["next_conf_c01"], fx["m8_next_conf_c01"], 1e-4, "next_conf_c01")
+    assert s8["i_ids"].cpu().tolist() == fx["m8_i_ids"].astype(np.int64).tolist()
+    assert s8["j_ids"].cpu().tolist() == fx["m8_j_ids"].astype(np.int64).tolist()
+
+
+@pytest.mark.gpu
+def test_cascade_stage_on_reference_tokens(fx):
+    """UpBlock + cascade transformer (window cross-attention around the reference's 1/8 argmax, 7x7 window self-attention) on
+    this model's own 1/4 backbone map and the fixture's 1/8 tokens; then the 1/4 matcher on the reference's 1/4 tokens."""
+    m = _model(fx, "cuda")
+    im0, im1 = _images(fx, "cuda")
+    data = {"image0": im0, "image1": im1}
+    t8 = torch.from_numpy(fx["t8"]).cuda().float()
+    idx = lambda k: torch.from_numpy(fx[k].astype(np.int64)).cuda()
+    with torch.no_grad():
+        _, (f4_0, f4_1), _ = m.features(data)
+        data["stage_8c"] = {"next_idx_c01": idx("m8_next_idx_c01"), "next_idx_c10": idx("m8_next_idx_c10"),
+                            "next_conf_c01": torch.from_numpy(fx["m8_next_conf_c01"]).cuda(), "next_conf_c01_s": None}
+        t0, t1 = m.cascade_stage(f4_0, f4_1, t8[:1], t8[1:], data)
+    _close(torch.cat([t0, t1]), fx["t4"].astype(np.float32), 3e-3, "1/4 tokens")
+    # the matcher on the reference's tokens and windows
+    t4 = torch.from_numpy(fx["t4"]).cuda().float()
+    from casmtr_amd import ops
+    H4, W4 = data["hw0_4c"]
+    wi = [ops.WindowIndex(ops.window_warp_idx(data["stage_8c"][k], H4 // 2, W4 // 2, 5), (H4, W4), (H4, W4), 1)
+          for k in ("next_idx_c01", "next_idx_c10")]
+    m.cascade_matching_4c(t4[:1].contiguous(), t4[1:].contiguous(), wi[0], wi[1], data, level="4c", pre_level="8c")
+    s4 = data["stage_4c"]
+    assert len(fx["m4_i_ids"]) >= 50
+    assert s4["i_ids"].cpu().tolist() == fx["m4_i_ids"].astype(np.int64).tolist()
+    assert s4["j_ids"].cpu().tolist() == fx["m4_j_ids"].astype(np.int64).tolist()
+    _close(s4["mconf"], fx["m4_mconf"], 1e-4, "mconf")
+    _close(s4["mkpts1_c"], fx["m4_mkpts1_c"], 0, "mkpts1_c")
+
+
+@pytest.mark.gpu
+def test_whole_forward(fx):
+    """free-running forward: fp32 differences of the GPU convolutions can flip near-tied selections, so this is a statistical
+    check -- the reference's matches are found again (same 1/4 cells, sub-pixel position within a quarter pixel)"""
+    m = _model(fx, "cuda")
+    im0, im1 = _images(fx, "cuda")
+    data = m({"image0": im0, "image1": im1})
+    mine = {(int(a[0]), int(a[1])): b for a, b in zip(data["mkpts0_f"].cpu().tolist(), data["mkpts1_f"].cpu())}
+    ref0, ref1 = fx["mkpts0_f"], torch.from_numpy(fx["mkpts1_f"])
+    hit = sum(1 for a, b in zip(ref0.tolist(), ref1) if (int(a[0]), int(a[1])) in mine
+              and float((mine[(int(a[0]), int(a[1]))] - b).abs().max()) < 0.25)
+    assert hit >= 0.9 * len(ref0), f"{hit} of {len(ref0)} reference matches reproduced ({len(mine)} found)"
+    assert abs(len(mine) - len(ref0)) <= 0.1 * len(ref0) + 2
