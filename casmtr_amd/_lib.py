@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcasmtr_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 ERR_UNSUPPORTED = 1001
 
-_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_P, _I, _F, _SZ, _LL = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
 # name -> (restype, argtypes): exactly the prototypes of include/casmtr_hip.h
 SIGNATURES = {
@@ -42,13 +42,15 @@ SIGNATURES = {
     "casmtr_nms_select_ws_bytes": (_SZ, [_I] * 3),
     "casmtr_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "casmtr_token_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "casmtr_dwconv3x3_tokens_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "casmtr_layer_norm_fwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _F, _P]),
     "casmtr_prof_enable": (None, [_I]),
     "casmtr_debug_set": (None, [_I]),
     "casmtr_prof_enable_only": (_I, [_I]),
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
 }
-PROF_COUNT = 16
+PROF_COUNT = 17
 
 
 def prof_enable(on: bool):

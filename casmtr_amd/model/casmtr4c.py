@@ -41,6 +41,19 @@ def outdoor_4c_config():
                            match_type="softmax", dsmax_temperature=1.0))
 
 
+def _fast(x):
+    """inference on the GPU: the token-major HIP element kernels apply (otherwise the same arithmetic on torch ops)"""
+    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+def _ln(norm, x, residual=None):
+    """norm(x) (+ residual)"""
+    if _fast(x) and x.shape[-1] % 4 == 0:
+        return ops.layer_norm(x.contiguous(), norm.weight, norm.bias, norm.eps, None if residual is None else residual.contiguous())
+    y = norm(x)
+    return y if residual is None else residual + y
+
+
 # ------------------------------------------------------------------------------------------------------------ backbone
 def _conv_bn(cin, cout, k, stride=1):
     return [nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False), nn.BatchNorm2d(cout)]
@@ -68,7 +81,7 @@ class _PatchEmbed(nn.Module):   # gvt.py:256-281
 
     def forward(self, x):
         H, W = x.shape[2] // self.patch, x.shape[3] // self.patch
-        return self.norm(self.proj(x).flatten(2).transpose(1, 2)), (H, W)
+        return _ln(self.norm, self.proj(x).flatten(2).transpose(1, 2)), (H, W)
 
 
 class _PosCNN(nn.Module):   # gvt.py:397-411, stride 1
@@ -78,6 +91,8 @@ class _PosCNN(nn.Module):   # gvt.py:397-411, stride 1
 
     def forward(self, x, H, W):
         B, N, C = x.shape
+        if _fast(x):
+            return ops.dwconv3x3_tokens(x.contiguous(), self.proj[0].weight, self.proj[0].bias, H, W, add_input=True)
         f = x.transpose(1, 2).reshape(B, C, H, W)
         return (self.proj(f) + f).flatten(2).transpose(1, 2)
 
@@ -140,7 +155,7 @@ class _ReducedAttention(nn.Module):
         B, N, C = x.shape
         nh = self.heads
         q = self.q(x).reshape(B, N, nh, C // nh).permute(0, 2, 1, 3)
-        r = self.norm(self.sr(x.permute(0, 2, 1).reshape(B, C, H, W)).reshape(B, C, -1).permute(0, 2, 1))
+        r = _ln(self.norm, self.sr(x.permute(0, 2, 1).reshape(B, C, H, W)).reshape(B, C, -1).permute(0, 2, 1))
         kv = self.kv(r).reshape(B, -1, 2, nh, C // nh).permute(2, 0, 3, 1, 4)
         att = ((q @ kv[0].transpose(-2, -1)) * self.scale).softmax(dim=-1)
         return self.proj((att @ kv[1]).transpose(1, 2).reshape(B, N, C))
@@ -154,8 +169,8 @@ class _TokenBlock(nn.Module):   # pre-norm transformer block on a token grid (Gr
         self.mlp = _TokenMlp(dim, 4 * dim)
 
     def forward(self, x, H, W):
-        x = x + self.attn(self.norm1(x), H, W)
-        return x + self.mlp(self.norm2(x))
+        x = x + self.attn(_ln(self.norm1, x), H, W)
+        return x + self.mlp(_ln(self.norm2, x))
 
 
 class _TwinsStages(nn.Module):
@@ -184,7 +199,7 @@ class _TwinsStages(nn.Module):
             x = self.blocks[i][0](x, H, W)
             x = self.pos_block[i](x, H, W)
             x = self.blocks[i][1](x, H, W)
-            x = self.norm_list[i](x).reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            x = _ln(self.norm_list[i], x).reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
             outs.append(x)
         return outs
 
@@ -252,7 +267,11 @@ class _ConvMlp(nn.Module):   # transformer.py:52-94: fc1 -> ReLU -> depth-wise 3
         self.fc1, self.dwconv, self.fc2 = nn.Linear(dim, hidden), _DWConv(hidden), nn.Linear(hidden, dim)
 
     def forward(self, x, H, W):
-        return self.fc2(F.gelu(self.dwconv(F.relu(self.fc1(x)), H, W)))
+        h = self.fc1(x)
+        if _fast(h):   # ReLU, the depth-wise convolution and GELU in one token-major pass
+            return self.fc2(ops.dwconv3x3_tokens(h.contiguous(), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W,
+                                                 pre_relu=True, post_gelu=True))
+        return self.fc2(F.gelu(self.dwconv(F.relu(h), H, W)))
 
 
 class QuadtreeBlock(nn.Module):   # transformer.py:141-196
@@ -263,8 +282,9 @@ class QuadtreeBlock(nn.Module):   # transformer.py:141-196
         self.mlp = _ConvMlp(dim, 4 * dim)
 
     def forward(self, x, target, H, W, H1, W1):
-        x = x + self.attn(self.norm1(x), self.norm1(target), H, W, H1, W1)
-        return x + self.mlp(self.norm2(x), H, W)
+        xn = _ln(self.norm1, x)
+        x = x + self.attn(xn, xn if target is x else _ln(self.norm1, target), H, W, H1, W1)
+        return x + self.mlp(_ln(self.norm2, x), H, W)
 
 
 class CascadeQuadtreeBlock(nn.Module):   # transformer.py:305-345
@@ -275,9 +295,9 @@ class CascadeQuadtreeBlock(nn.Module):   # transformer.py:305-345
         self.mlp = _ConvMlp(dim, 4 * dim)
 
     def forward(self, x, target, H, W, H1, W1, idx):
-        y, _ = self.attn(self.norm1(x), self.norm1(target), H, W, H1, W1, idx, None, want_idx=False)
+        y, _ = self.attn(_ln(self.norm1, x), _ln(self.norm1, target), H, W, H1, W1, idx, None, want_idx=False)
         x = x + y
-        return x + self.mlp(self.norm2(x), H, W)
+        return x + self.mlp(_ln(self.norm2, x), H, W)
 
 
 class LocalBlock(nn.Module):   # cascade_attention.py:240-248: window self-attention, ws = attn_window_size
@@ -355,8 +375,8 @@ class _EncoderLayer(nn.Module):   # LoFTREncoderLayer with full attention (trans
         h, d = self.heads, C // self.heads
         q, k, v = self.q_proj(x).view(B, L, h, d), self.k_proj(src).view(B, -1, h, d), self.v_proj(src).view(B, -1, h, d)
         att = torch.softmax(torch.einsum("nlhd,nshd->nlsh", q, k) / d ** 0.5, dim=2)
-        msg = self.norm1(self.merge(torch.einsum("nlsh,nshd->nlhd", att, v).reshape(B, L, C)))
-        return x + self.norm2(self.mlp(torch.cat([x, msg], dim=2)))
+        msg = _ln(self.norm1, self.merge(torch.einsum("nlsh,nshd->nlhd", att, v).reshape(B, L, C)))
+        return _ln(self.norm2, self.mlp(torch.cat([x, msg], dim=2)), residual=x)
 
 
 class FineTransformer(nn.Module):

@@ -199,6 +199,34 @@ def token_pool_multi(xs, H, W):
     return ys
 
 
+def dwconv3x3_tokens(x, weight, bias, H, W, pre_relu=False, post_gelu=False, add_input=False):
+    """depth-wise 3x3 (stride 1, zero pad 1) on token-major x [B,H*W,C]; weight [C,1,3,3]; optional fused ReLU-in / GELU-out /
+    + input (Mlp's DWConv, PosCNN)."""
+    _chk(x, "x"), _chk(weight, "weight"), _chk(bias, "bias")
+    B, HW, Cc = x.shape
+    if HW != H * W or weight.numel() != 9 * Cc:
+        raise RuntimeError("dwconv3x3_tokens: x must be [B, H*W, C] and weight [C, 1, 3, 3]")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().casmtr_dwconv3x3_tokens_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), B, H, W, Cc,
+                                                          int(pre_relu) | 2 * int(post_gelu) | 4 * int(add_input), _stream()),
+                   "dwconv3x3_tokens_fwd")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None):
+    """nn.LayerNorm over the last axis of a contiguous fp32 tensor, optionally + residual (same shape) after the affine map."""
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(residual, "residual")
+    Cc = x.shape[-1]
+    if residual is not None and residual.shape != x.shape:
+        raise RuntimeError("layer_norm: residual must have x's shape")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().casmtr_layer_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(y), x.numel() // Cc, Cc,
+                                                    float(eps), _stream()), "layer_norm_fwd")
+    return y
+
+
 def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
     """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")

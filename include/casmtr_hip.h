@@ -171,6 +171,25 @@ int casmtr_linear_fwd(const float* const* x, const float* const* w, const float*
 int casmtr_token_pool_fwd(const float* const* src, float* const* dst, int n, int B, int H, int W, int C,
                           casmtr_stream_t stream);
 
+/* Depth-wise 3x3 convolution (stride 1, zero padding 1) on token-major data: x, y [B,H*W,C], w [C,1,3,3] viewed as [C,9],
+ * bias [C] or NULL.  Replaces DWConv (transformer.py:52-63: transpose to NCHW, nn.Conv2d(groups=C), transpose back) inside
+ * Mlp (:65-94, fc1 -> ReLU -> DWConv -> GELU -> fc2) and PosCNN (gvt.py:397-411, x + DWConv(x)):
+ *   acc = bias[c]; for ky,kx row-major: acc = fmaf(in(y+ky-1, x+kx-1, c), w[c][3ky+kx], acc), taps outside the grid skipped;
+ *   CASMTR_DW_PRE_RELU: in() = max(x, 0);  CASMTR_DW_POST_GELU: erf-form GELU of acc;  CASMTR_DW_ADD_INPUT: + x[y,x,c] last.
+ * C % 4 == 0, y != x.                                                                                                  */
+#define CASMTR_DW_PRE_RELU 1
+#define CASMTR_DW_POST_GELU 2
+#define CASMTR_DW_ADD_INPUT 4
+int casmtr_dwconv3x3_tokens_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                                int flags, casmtr_stream_t stream);
+
+/* nn.LayerNorm over the last axis of x [rows, C] (norm1 / norm2 of QuadtreeBlock and CascadeQuadtreeBlock,
+ * transformer.py:141-196, 305-345), optionally + residual [rows, C] after the affine map (x + norm(...) patterns):
+ *   mean = (sum x) / C; var = (sum (x - mean)^2) / C; y = (x - mean) * (1 / sqrt(var + eps)) * gamma + beta (+ residual).
+ * C % 4 == 0, C <= 1024; y may alias x or residual.                                                                   */
+int casmtr_layer_norm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                          long long rows, int C, float eps, casmtr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart): per-kernel launch durations from HIP events recorded on the
  * launch stream.  Off by default.  casmtr_prof_enable(1) starts a fresh collection; casmtr_prof_read() waits for
@@ -181,7 +200,8 @@ enum {
     CASMTR_PROF_DS_GEMM = 0, CASMTR_PROF_DS_REDUCE, CASMTR_PROF_DS_CONF, CASMTR_PROF_DS_SELECT,
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
-    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED, CASMTR_PROF_COUNT
+    CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED,
+    CASMTR_PROF_GLUE, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
 /* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).

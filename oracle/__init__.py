@@ -291,6 +291,28 @@ def token_pool(x, H, W):
     return out
 
 
+def dwconv3x3_tokens(x, w, bias, H, W, pre_relu=False, post_gelu=False, add_input=False):
+    """DWConv of Mlp / PosCNN on token-major [B,H*W,C] (transformer.py:52-94, gvt.py:397-411); w [C,1,3,3] or [C,9]."""
+    x, w = _f(x), _f(np.asarray(w).reshape(-1, 9))
+    B, _, Cc = x.shape
+    bias = None if bias is None else _f(bias)
+    out = np.empty_like(x)
+    lib().orc_dwconv3x3_tokens(_p(x), _p(w), _p(bias) if bias is not None else None, _p(out), *_ci(B, H, W, Cc),
+                               C.c_int(int(pre_relu) | 2 * int(post_gelu) | 4 * int(add_input)))
+    return out
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None):
+    """nn.LayerNorm over the last axis (+ residual), double accumulation."""
+    x, gamma, beta = _f(x), _f(gamma), _f(beta)
+    residual = None if residual is None else _f(residual)
+    out = np.empty_like(x)
+    Cc = x.shape[-1]
+    lib().orc_layer_norm(_p(x), _p(gamma), _p(beta), _p(residual) if residual is not None else None, _p(out),
+                         C.c_int64(x.size // Cc), C.c_int(Cc), C.c_float(eps))
+    return out
+
+
 def _nchw(t, h, w):
     B, _, Cc = t.shape
     return np.ascontiguousarray(t.reshape(B, h, w, Cc).transpose(0, 3, 1, 2))

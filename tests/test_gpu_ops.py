@@ -404,3 +404,55 @@ def test_window_match_implicit_windows(ops, monkeypatch, C, ws, masks, dil, reci
     assert_close(N(d["next_conf"]), o["next_conf"], SOFTMAX_TOL, "next_conf")
     n = ops.window_match(T(fq), T(fk), wi, 1.0, want_conf=False, **kw)
     assert n["conf_matrix"] is None and torch.equal(n["next_idx"], d["next_idx"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# token-major element kernels of the calling blocks (glue.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 13, 11, 64), (1, 24, 32, 256), (2, 7, 8, 1024), (1, 3, 1, 8)])
+@pytest.mark.parametrize("flags", [(False, False, False), (True, True, False), (False, False, True), (True, True, True)])
+def test_dwconv3x3_tokens_vs_oracle_and_torch(B, H, W, Cc, flags):
+    import oracle
+    from casmtr_amd import ops
+    r = np.random.RandomState(B * 1000 + H * 10 + Cc)
+    x = r.standard_normal((B, H * W, Cc)).astype(np.float32)
+    w = (r.standard_normal((Cc, 1, 3, 3)) / 3).astype(np.float32)
+    b = (0.1 * r.standard_normal(Cc)).astype(np.float32)
+    pre, post, add = flags
+    want = oracle.dwconv3x3_tokens(x, w, b, H, W, pre, post, add)
+    xt, wt, bt = (torch.from_numpy(a).cuda() for a in (x, w, b))
+    got = ops.dwconv3x3_tokens(xt, wt, bt, H, W, pre, post, add)
+    if post:   # erff: device libm vs glibc differ in the last ulps
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-7)
+    else:
+        assert np.array_equal(got.cpu().numpy(), want)
+    # torch's own formulation (NCHW conv2d): tolerance only, its accumulation order is the library's
+    f = xt.transpose(1, 2).reshape(B, Cc, H, W)
+    f = torch.relu(f) if pre else f
+    ref = torch.nn.functional.conv2d(f, wt, bt, padding=1, groups=Cc)
+    ref = torch.nn.functional.gelu(ref) if post else ref
+    ref = ref.flatten(2).transpose(1, 2) + (xt if add else 0)
+    assert float((got - ref).abs().max()) < 1e-4
+    # no bias
+    got0 = ops.dwconv3x3_tokens(xt, wt, None, H, W, pre, post, add)
+    want0 = oracle.dwconv3x3_tokens(x, w, None, H, W, pre, post, add)
+    np.testing.assert_allclose(got0.cpu().numpy(), want0, rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,Cc", [(37, 64), (1000, 128), (513, 256), (9, 1024), (5, 8), (64, 520)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layer_norm_vs_oracle_and_torch(rows, Cc, with_res):
+    import oracle
+    from casmtr_amd import ops
+    r = np.random.RandomState(rows + Cc)
+    x = (r.standard_normal((rows, Cc)) * 2 + 0.5).astype(np.float32)
+    g, b = (1 + 0.1 * r.standard_normal(Cc)).astype(np.float32), (0.1 * r.standard_normal(Cc)).astype(np.float32)
+    res = r.standard_normal((rows, Cc)).astype(np.float32) if with_res else None
+    want = oracle.layer_norm(x, g, b, 1e-5, res)
+    xt, gt, bt = (torch.from_numpy(a).cuda() for a in (x, g, b))
+    rt = torch.from_numpy(res).cuda() if with_res else None
+    got = ops.layer_norm(xt, gt, bt, 1e-5, rt)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    ref = torch.nn.functional.layer_norm(xt, (Cc,), gt, bt, 1e-5) + (rt if with_res else 0)
+    assert float((got - ref).abs().max()) < 1e-5
