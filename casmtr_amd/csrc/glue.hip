@@ -174,3 +174,111 @@ extern "C" int casmtr_layer_norm_fwd(const float* x, const float* gamma, const f
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Window self-attention of the local blocks (GroupAttention.forward_mask: src/model/modules/cascade_attention.py:124-157,
+// src/model/backbone/gvt.py:102-133) on the un-padded token-major output of the fused qkv projection.
+// The reference zero-pads the grid to a multiple of ws, projects the padding too, builds the [windows, ws^2, ws^2] -1000 mask,
+// and materialises Q.K^T, the scaled copy, the masked copy, the softmax and the permuted output.  For a real query the mask
+// removes exactly the padded keys (exp(-1000 - max) == 0 in fp32), so the result is the softmax over the real tokens of the
+// window -- which is what this kernel computes, without ever touching padding:
+//   s_j = (chain_d fmaf(q[d], k_j[d])) * scale;  p_j = exp(s_j - max_j s);  o = (sum_j p_j v_j) * (1 / sum_j p_j),  j in window raster order.
+// One wave per (window, head): lane <-> query token of the window (ws^2 <= 64), K / V rows of the head staged in LDS by
+// coalesced 8-lanes-per-row loads and read back as broadcasts; head_dim = 32.
+template <int WS>
+__global__ __launch_bounds__(256) void window_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int H, int W,
+                                                          int NH, int GW, int GH, float scale) {
+    constexpr int T = WS * WS;
+    __shared__ float kv[4][2][T][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int win = blockIdx.x;
+    const int wx = win % GW, wy = (win / GW) % GH, b = win / (GW * GH);
+    const int C = NH * 32;
+    const size_t row_stride = (size_t)3 * C;                       // floats between consecutive tokens of qkv
+    const float* base = qkv + (size_t)b * H * W * row_stride;
+    float* obase = out + (size_t)b * H * W * C;
+    const int rows = min(WS, H - wy * WS), cols = min(WS, W - wx * WS);
+    const int n = rows * cols;                                     // real tokens of this window
+    for (int h = wave; h < NH; h += 4) {
+        // stage K and V rows: 8 lanes per 128-byte row
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            const int j = j0 + (lane >> 3);
+            if (j < n) {
+                const int ty = wy * WS + j / cols, tx = wx * WS + j % cols;
+                const float* src = base + ((size_t)ty * W + tx) * row_stride + h * 32 + (lane & 7) * 4;
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(src + C);
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * C);
+                *reinterpret_cast<f32x4*>(&kv[wave][0][j][(lane & 7) * 4]) = kk;
+                *reinterpret_cast<f32x4*>(&kv[wave][1][j][(lane & 7) * 4]) = vv;
+            }
+        }
+        const bool act = lane < n;
+        const int qi = act ? lane : 0;
+        const int qy = wy * WS + qi / cols, qx = wx * WS + qi % cols;
+        const size_t tok = (size_t)qy * W + qx;
+        float q[32];
+        {
+            const f32x4* qp = reinterpret_cast<const f32x4*>(base + tok * row_stride + h * 32);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const f32x4 t = qp[p];
+                q[4 * p] = t[0]; q[4 * p + 1] = t[1]; q[4 * p + 2] = t[2]; q[4 * p + 3] = t[3];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        float s[T];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            float a = 0.f;
+            if (j < n) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const f32x4 kk = *reinterpret_cast<const f32x4*>(&kv[wave][0][j][4 * p]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fmaf(q[4 * p + e], kk[e], a);
+                }
+                a *= scale;
+                m = fmaxf(m, a);
+            }
+            s[j] = a;
+        }
+        float o[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            if (j < n) {
+                const float p = __expf(s[j] - m);
+                sum += p;
+#pragma unroll
+                for (int pz = 0; pz < 8; ++pz) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(&kv[wave][1][j][4 * pz]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[4 * pz + e] = fmaf(p, vv[e], o[4 * pz + e]);
+                }
+            }
+        }
+        const float inv = 1.0f / sum;
+        if (act) {
+            f32x4* op = reinterpret_cast<f32x4*>(obase + tok * C + h * 32);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) op[p] = f32x4{o[4 * p] * inv, o[4 * p + 1] * inv, o[4 * p + 2] * inv, o[4 * p + 3] * inv};
+        }
+        __builtin_amdgcn_wave_barrier();                           // all lanes done with kv[wave] before the next head overwrites it
+    }
+}
+
+extern "C" int casmtr_window_attn_fwd(const float* qkv, float* out, int B, int H, int W, int nhead, int head_dim, int ws, float scale,
+                                      casmtr_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (head_dim != 32 || ws != 7 || nhead <= 0) return CASMTR_ERR_UNSUPPORTED;
+    const int GW = (W + ws - 1) / ws, GH = (H + ws - 1) / ws;
+    ProfScope ps(CASMTR_PROF_GLUE, (hipStream_t)stream);
+    hipLaunchKernelGGL(window_attn_kernel<7>, dim3((unsigned)(B * GW * GH)), dim3(256), 0, (hipStream_t)stream, qkv, out, H, W, nhead,
+                       GW, GH, scale);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}

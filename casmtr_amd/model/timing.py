@@ -1,0 +1,60 @@
+"""Whole-model timing of CasMTR4c: random-init weights, synthetic image pairs, per-stage HIP-event breakdown.
+A SECOND metric next to bench.py's hot-path line -- it includes the torch-op glue (backbone convolutions, MLP GEMMs, window
+self-attention) that the hot-path step leaves out.  Used by bench.py ('whole_model' object) and tools/model_e2e_time.py."""
+import torch
+
+from .casmtr4c import CasMTR4c, outdoor_4c_config
+
+
+def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda"):
+    cfg = outdoor_4c_config()
+    if coarse_thr is not None:
+        cfg["match_coarse"]["thr"] = coarse_thr
+    if cascade_thr is not None:
+        cfg["match_cascade"].update(test_thr=cascade_thr, pre_thr=[0.0])
+    torch.manual_seed(0)
+    m = CasMTR4c(cfg).eval().to(device)
+    g = torch.Generator(device=device).manual_seed(1)
+    mk = lambda: torch.rand((batch, 3, size, size), device=device, generator=g)
+    sets = [(mk(), mk()) for _ in range(2)]
+    names = ["backbone", "stage_8c", "stage_4c", "fine"]
+    acc = dict.fromkeys(names, 0.0)
+    nm = 0
+
+    def step(i, timed):
+        nonlocal nm
+        im0, im1 = sets[i % 2]
+        data = {"image0": im0, "image1": im1}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        with torch.no_grad():
+            ev[0].record()
+            (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1) = m.features(data)
+            ev[1].record()
+            t8 = m.coarse_stage(f8_0, f8_1, data)
+            ev[2].record()
+            t4 = m.cascade_stage(f4_0, f4_1, *t8, data)
+            ev[3].record()
+            m.fine_stage(ff0, ff1, *t4, data)
+            ev[4].record()
+        torch.cuda.synchronize()
+        if timed:
+            for k, n in enumerate(names):
+                acc[n] += ev[k].elapsed_time(ev[k + 1])
+            nm += int(data["mkpts0_f"].shape[0])
+
+    for i in range(warmup):
+        step(i, False)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for i in range(steps):
+        step(i, True)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / steps
+    out = {"metric": "whole-model image pairs/sec (CasMTR-4c: torch glue + HIP hot path, fp32)", "value": round(batch / ms * 1e3, 2),
+           "unit": "pairs/s", "ms_per_step": round(ms, 2), "batch": batch, "size": size, "steps": steps,
+           "stage_ms": {k: round(v / steps, 2) for k, v in acc.items()}, "matches_per_pair": round(nm / steps / batch, 1),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "data": "synthetic", "weights": "random-init"}
+    del m, sets
+    torch.cuda.empty_cache()
+    return out

@@ -227,6 +227,20 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None):
     return y
 
 
+def window_attn(qkv, H, W, nhead, ws, scale):
+    """window self-attention on the fused projection qkv [B,H*W,3*C] of un-padded tokens -> [B,H*W,C] (head_dim 32, ws 7)."""
+    _chk(qkv, "qkv")
+    B, HW, C3 = qkv.shape
+    Cc = C3 // 3
+    if HW != H * W or C3 != 3 * Cc or Cc % nhead:
+        raise RuntimeError("window_attn: qkv must be [B, H*W, 3*C]")
+    y = torch.empty((B, HW, Cc), device=qkv.device, dtype=torch.float32)
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.lib().casmtr_window_attn_fwd(_ptr(qkv), _ptr(y), B, H, W, nhead, Cc // nhead, ws, float(scale), _stream()),
+                   "window_attn_fwd")
+    return y
+
+
 def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
     """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")

@@ -190,6 +190,15 @@ int casmtr_dwconv3x3_tokens_fwd(const float* x, const float* w, const float* bia
 int casmtr_layer_norm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                           long long rows, int C, float eps, casmtr_stream_t stream);
 
+/* Window self-attention of the local blocks (GroupAttention.forward_mask, cascade_attention.py:124-157 / gvt.py:102-133):
+ * qkv [B,H*W,3,nhead,head_dim] = the fused projection of the UN-padded tokens, out [B,H*W,nhead*head_dim].  Tokens are grouped
+ * in ws x ws windows anchored at (0,0); windows cut by the bottom / right edge hold fewer tokens (the reference pads them and
+ * masks the padded keys with -1000, i.e. exp() == 0 exactly: same result for every real token).
+ *   s_j = (chain_d fmaf(q[d], k_j[d])) * scale; p_j = exp(s_j - max s); o = (sum_j p_j v_j) * (1 / sum_j p_j), j in window raster order.
+ * head_dim == 32 and ws == 7 (every shipped config), otherwise CASMTR_ERR_UNSUPPORTED.                                      */
+int casmtr_window_attn_fwd(const float* qkv, float* out, int B, int H, int W, int nhead, int head_dim, int ws, float scale,
+                           casmtr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart): per-kernel launch durations from HIP events recorded on the
  * launch stream.  Off by default.  casmtr_prof_enable(1) starts a fresh collection; casmtr_prof_read() waits for

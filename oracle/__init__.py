@@ -313,6 +313,17 @@ def layer_norm(x, gamma, beta, eps=1e-5, residual=None):
     return out
 
 
+def window_attn(qkv, H, W, nhead, ws, scale):
+    """GroupAttention.forward_mask for the real tokens (cascade_attention.py:124-157): qkv [B,H*W,3*C] -> [B,H*W,C]."""
+    qkv = _f(qkv)
+    B, HW, C3 = qkv.shape
+    Cc = C3 // 3
+    assert ws * ws <= 64 and Cc // nhead <= 64
+    out = np.empty((B, HW, Cc), np.float32)
+    lib().orc_window_attn(_p(qkv), _p(out), *_ci(B, H, W, nhead, Cc // nhead, ws), C.c_float(scale))
+    return out
+
+
 def _nchw(t, h, w):
     B, _, Cc = t.shape
     return np.ascontiguousarray(t.reshape(B, h, w, Cc).transpose(0, 3, 1, 2))

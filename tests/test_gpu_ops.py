@@ -456,3 +456,45 @@ def test_layer_norm_vs_oracle_and_torch(rows, Cc, with_res):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
     ref = torch.nn.functional.layer_norm(xt, (Cc,), gt, bt, 1e-5) + (rt if with_res else 0)
     assert float((got - ref).abs().max()) < 1e-5
+
+
+def _window_attn_torch(qkv, H, W, nh, ws, scale):
+    """the reference's padded + masked formulation (GroupAttention.forward_mask), restated on torch ops"""
+    import torch.nn.functional as F
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(qkv.view(B, H, W, C3), (0, 0, 0, pr, 0, pb))
+    Hp, Wp = H + pb, W + pr
+    gh, gw = Hp // ws, Wp // ws
+    pad = torch.zeros((1, Hp, Wp), device=qkv.device)
+    if pb:
+        pad[:, -pb:, :] = 1
+    if pr:
+        pad[:, :, -pr:] = 1
+    pad = pad.reshape(1, gh, ws, gw, ws).transpose(2, 3).reshape(1, gh * gw, ws * ws)
+    bias = pad.unsqueeze(2) - pad.unsqueeze(3)
+    bias = torch.where(bias != 0, torch.full_like(bias, -1000.0), torch.zeros_like(bias))
+    t = x.reshape(B, gh, ws, gw, ws, 3, nh, Cc // nh).transpose(2, 3).reshape(B, gh * gw, ws * ws, 3, nh, Cc // nh).permute(3, 0, 1, 4, 2, 5)
+    att = ((t[0] @ t[1].transpose(-2, -1)) * scale + bias.unsqueeze(2)).softmax(dim=-1)
+    out = (att @ t[2]).transpose(2, 3).reshape(B, gh, gw, ws, ws, Cc).transpose(2, 3).reshape(B, Hp, Wp, Cc)
+    return out[:, :H, :W, :].reshape(B, N, Cc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,nh", [(2, 14, 21, 4), (1, 24, 32, 8), (2, 13, 9, 4), (1, 5, 3, 2), (1, 52, 52, 4)])
+def test_window_attn_vs_oracle_and_torch(B, H, W, nh):
+    import oracle
+    from casmtr_amd import ops
+    r = np.random.RandomState(H * 100 + W)
+    Cc = nh * 32
+    qkv = r.standard_normal((B, H * W, 3 * Cc)).astype(np.float32)
+    scale = 32 ** -0.5
+    want = oracle.window_attn(qkv, H, W, nh, 7, scale)
+    qt = torch.from_numpy(qkv).cuda()
+    got = ops.window_attn(qt, H, W, nh, 7, scale)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-6)
+    ref = _window_attn_torch(qt, H, W, nh, 7, scale)
+    assert float((got - ref).abs().max()) < 2e-5
+    with pytest.raises(RuntimeError):
+        ops.window_attn(qt, H, W, nh, 5, scale)
