@@ -46,6 +46,16 @@ def _fast(x):
     return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
 
 
+def _tokens(f):
+    """[B,C,H,W] -> [B,H*W,C]; a view when f is channels_last"""
+    return f.permute(0, 2, 3, 1).reshape(f.shape[0], -1, f.shape[1])
+
+
+def _grid(t, H, W):
+    """[B,H*W,C] tokens -> [B,C,H,W] as a channels_last view (no copy; MIOpen convolutions take it as is)"""
+    return t.reshape(t.shape[0], H, W, t.shape[2]).permute(0, 3, 1, 2)
+
+
 def _ln(norm, x, residual=None):
     """norm(x) (+ residual)"""
     if _fast(x) and x.shape[-1] % 4 == 0:
@@ -81,7 +91,7 @@ class _PatchEmbed(nn.Module):   # gvt.py:256-281
 
     def forward(self, x):
         H, W = x.shape[2] // self.patch, x.shape[3] // self.patch
-        return _ln(self.norm, self.proj(x).flatten(2).transpose(1, 2)), (H, W)
+        return _ln(self.norm, _tokens(self.proj(x))), (H, W)
 
 
 class _PosCNN(nn.Module):   # gvt.py:397-411, stride 1
@@ -93,8 +103,8 @@ class _PosCNN(nn.Module):   # gvt.py:397-411, stride 1
         B, N, C = x.shape
         if _fast(x):
             return ops.dwconv3x3_tokens(x.contiguous(), self.proj[0].weight, self.proj[0].bias, H, W, add_input=True)
-        f = x.transpose(1, 2).reshape(B, C, H, W)
-        return (self.proj(f) + f).flatten(2).transpose(1, 2)
+        f = _grid(x, H, W)
+        return _tokens(self.proj(f) + f)
 
 
 class _TokenMlp(nn.Module):   # fc1 -> GELU -> fc2 (gvt.py:47-63, cascade_attention.py:10-25)
@@ -157,10 +167,11 @@ class _ReducedAttention(nn.Module):
         B, N, C = x.shape
         nh = self.heads
         q = self.q(x).reshape(B, N, nh, C // nh).permute(0, 2, 1, 3)
-        r = _ln(self.norm, self.sr(x.permute(0, 2, 1).reshape(B, C, H, W)).reshape(B, C, -1).permute(0, 2, 1))
+        r = _ln(self.norm, _tokens(self.sr(_grid(x, H, W))))
         kv = self.kv(r).reshape(B, -1, 2, nh, C // nh).permute(2, 0, 3, 1, 4)
-        att = ((q @ kv[0].transpose(-2, -1)) * self.scale).softmax(dim=-1)
-        return self.proj((att @ kv[1]).transpose(1, 2).reshape(B, N, C))
+        # softmax(q k^T * scale) v without the [B, heads, N, N/sr^2] matrix in HBM (7.5 GB at 832x832, batch 8)
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=self.scale)
+        return self.proj(o.transpose(1, 2).reshape(B, N, C))
 
 
 class _TokenBlock(nn.Module):   # pre-norm transformer block on a token grid (GroupBlock, gvt.py:239-253 / cascade_attention.py:214-228)
@@ -201,7 +212,7 @@ class _TwinsStages(nn.Module):
             x = self.blocks[i][0](x, H, W)
             x = self.pos_block[i](x, H, W)
             x = self.blocks[i][1](x, H, W)
-            x = _ln(self.norm_list[i], x).reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            x = _grid(_ln(self.norm_list[i], x), H, W)
             outs.append(x)
         return outs
 
@@ -223,7 +234,7 @@ class TwinsFPN(nn.Module):   # twins_fpn.py:75-180 -> [1/8 (C=256), 1/4 (C=128),
     def forward(self, x):
         mean = x.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
         std = x.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-        x = (x - mean) / std
+        x = ((x - mean) / std).contiguous(memory_format=torch.channels_last)
         x1 = self.layer1(self.conv1(x))
         x2, x3 = self.vit.forward_features(x)
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="bilinear", align_corners=True)
@@ -249,7 +260,7 @@ class SinePositionEncoding(nn.Module):   # position_encoding.py:55-85 (positions
             pe = torch.zeros((self.d_model, H, W))
             pe[0::4], pe[1::4] = torch.sin(xpos * div), torch.cos(xpos * div)
             pe[2::4], pe[3::4] = torch.sin(ypos * div), torch.cos(ypos * div)
-            self._pe = pe.unsqueeze(0).to(x.device)
+            self._pe = pe.unsqueeze(0).to(x.device).contiguous(memory_format=torch.channels_last)
         return x + self._pe
 
 
@@ -260,7 +271,7 @@ class _DWConv(nn.Module):
 
     def forward(self, x, H, W):
         B, N, C = x.shape
-        return self.dwconv(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+        return _tokens(self.dwconv(_grid(x, H, W)))
 
 
 class _ConvMlp(nn.Module):   # transformer.py:52-94: fc1 -> ReLU -> depth-wise 3x3 -> GELU -> fc2
@@ -319,7 +330,7 @@ class CoarseTransformer(nn.Module):   # LocalFeatureTransformer, block_type 'qua
 
     def forward(self, f0, f1):
         (H0, W0), (H1, W1) = f0.shape[2:], f1.shape[2:]
-        f0, f1 = f0.flatten(2).transpose(1, 2), f1.flatten(2).transpose(1, 2)
+        f0, f1 = _tokens(f0).contiguous(), _tokens(f1).contiguous()
         for layer, name in zip(self.layers, self.layer_names):
             if name == "self":
                 f0, f1 = layer(f0, f0, H0, W0, H0, W0), layer(f1, f1, H1, W1, H1, W1)
@@ -341,7 +352,7 @@ class CascadeTransformer(nn.Module):   # CascadeFeatureTransformer, 'window' pro
 
     def forward(self, f0, f1, next_idx_c01, next_idx_c10):
         (H0, W0), (H1, W1) = f0.shape[2:], f1.shape[2:]
-        f0, f1 = f0.flatten(2).transpose(1, 2), f1.flatten(2).transpose(1, 2)
+        f0, f1 = _tokens(f0).contiguous(), _tokens(f1).contiguous()
         tp01 = ops.window_warp_idx(next_idx_c01.contiguous(), H0 // 2, W0 // 2, self.ws)   # get_window_warp_idx, :416-440
         tp10 = ops.window_warp_idx(next_idx_c10.contiguous(), H1 // 2, W1 // 2, self.ws)
         for layer, name in zip(self.layers, self.layer_names):
@@ -496,9 +507,8 @@ class CasMTR4c(nn.Module):
     def cascade_stage(self, f4_0, f4_1, t8_0, t8_1, data):
         """1/4: up-sample the 1/8 tokens into the 1/4 features, cascade transformer around the 1/8 argmax, window matching + NMS
         -> tokens [B, HW, C] x 2; data['stage_4c']"""
-        g = lambda t, hw: t.transpose(1, 2).reshape(t.shape[0], t.shape[2], *hw)
-        f4_0 = self.up_block1(f4_0, g(t8_0, data["hw0_8c"]))
-        f4_1 = self.up_block1(f4_1, g(t8_1, data["hw1_8c"]))
+        f4_0 = self.up_block1(f4_0, _grid(t8_0, *data["hw0_8c"]))
+        f4_1 = self.up_block1(f4_1, _grid(t8_1, *data["hw1_8c"]))
         st8 = data["stage_8c"]
         t0, t1, idx01, idx10 = self.loftr_coarse_4c(self.pos_encoding_4c(f4_0), self.pos_encoding_4c(f4_1),
                                                     st8["next_idx_c01"], st8["next_idx_c10"])
