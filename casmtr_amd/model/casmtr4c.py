@@ -56,6 +56,13 @@ def _grid(t, H, W):
     return t.reshape(t.shape[0], H, W, t.shape[2]).permute(0, 3, 1, 2)
 
 
+def _lin(layer, x):
+    """nn.Linear on tokens: the package's fp32-MFMA NT GEMM (bias in the epilogue) for the big token matrices"""
+    if _fast(x) and x.shape[-1] % 32 == 0 and x.numel() // x.shape[-1] >= 4096:
+        return ops.linear(x.contiguous(), layer.weight, layer.bias)
+    return layer(x)
+
+
 def _ln(norm, x, residual=None):
     """norm(x) (+ residual)"""
     if _fast(x) and x.shape[-1] % 4 == 0:
@@ -113,7 +120,7 @@ class _TokenMlp(nn.Module):   # fc1 -> GELU -> fc2 (gvt.py:47-63, cascade_attent
         self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return _lin(self.fc2, F.gelu(_lin(self.fc1, x)))
 
 
 class _WindowAttention(nn.Module):
@@ -130,7 +137,7 @@ class _WindowAttention(nn.Module):
         B, N, C = x.shape
         ws, nh = self.ws, self.heads
         if _fast(x) and ws == 7 and C // nh == 32:   # one kernel on the un-padded tokens; no mask, no attention matrix in HBM
-            return self.proj(ops.window_attn(self.qkv(x).contiguous(), H, W, nh, ws, self.scale))
+            return _lin(self.proj, ops.window_attn(_lin(self.qkv, x), H, W, nh, ws, self.scale))
         pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
         x = F.pad(x.view(B, H, W, C), (0, 0, 0, pr, 0, pb))
         Hp, Wp = H + pb, W + pr
@@ -166,12 +173,12 @@ class _ReducedAttention(nn.Module):
     def forward(self, x, H, W):
         B, N, C = x.shape
         nh = self.heads
-        q = self.q(x).reshape(B, N, nh, C // nh).permute(0, 2, 1, 3)
+        q = _lin(self.q, x).reshape(B, N, nh, C // nh).permute(0, 2, 1, 3)
         r = _ln(self.norm, _tokens(self.sr(_grid(x, H, W))))
         kv = self.kv(r).reshape(B, -1, 2, nh, C // nh).permute(2, 0, 3, 1, 4)
         # softmax(q k^T * scale) v without the [B, heads, N, N/sr^2] matrix in HBM (7.5 GB at 832x832, batch 8)
         o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=self.scale)
-        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+        return _lin(self.proj, o.transpose(1, 2).reshape(B, N, C))
 
 
 class _TokenBlock(nn.Module):   # pre-norm transformer block on a token grid (GroupBlock, gvt.py:239-253 / cascade_attention.py:214-228)
@@ -280,10 +287,10 @@ class _ConvMlp(nn.Module):   # transformer.py:52-94: fc1 -> ReLU -> depth-wise 3
         self.fc1, self.dwconv, self.fc2 = nn.Linear(dim, hidden), _DWConv(hidden), nn.Linear(hidden, dim)
 
     def forward(self, x, H, W):
-        h = self.fc1(x)
+        h = _lin(self.fc1, x)
         if _fast(h):   # ReLU, the depth-wise convolution and GELU in one token-major pass
-            return self.fc2(ops.dwconv3x3_tokens(h.contiguous(), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W,
-                                                 pre_relu=True, post_gelu=True))
+            return _lin(self.fc2, ops.dwconv3x3_tokens(h.contiguous(), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, H, W,
+                                                       pre_relu=True, post_gelu=True))
         return self.fc2(F.gelu(self.dwconv(F.relu(h), H, W)))
 
 
