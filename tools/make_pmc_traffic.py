@@ -3,14 +3,14 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes).  HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024 (gfx950: FETCH_SIZE
 reports half of a wide coalesced read; calibrated here on ds_conf_kernel, which reads exactly 4*L*S*B bytes) + WRITE_SIZE[KB] * 1024.
 
-    tools/make_pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv profiles/pmc_traffic.json
+    tools/make_pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv profiles/pmc_traffic.json [round-tag]
 """
 import csv
 import json
 import sys
 from collections import defaultdict
 
-BENCH_NAME = [("quad_attn_kernel<8, 64, 0>", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 128, 0>", "quad_attn_kernel<fine>"),
+BENCH_NAME = [("fine_level_dma_kernel", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 64, 0>", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 128, 0>", "quad_attn_kernel<fine>"),
               ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
               ("coarse_fused_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
               ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
@@ -41,5 +41,6 @@ for k in sorted(set(fetch) | set(write)):
     w, nw = write.get(k, (0.0, 0))
     out[k] = {"hbm_bytes_per_launch": round(2 * f * 1024 + w * 1024), "fetch_KB_raw": round(f, 1), "write_KB_raw": round(w, 1),
               "launches_sampled": max(nf, nw)}
+out["_round"] = sys.argv[4] if len(sys.argv) > 4 else "unlabelled"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
