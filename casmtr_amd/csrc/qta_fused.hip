@@ -24,6 +24,11 @@ int casmtr_qta_fine_level_dma(const float* q, const float* key, const float* val
                               float w_level, const float* acc_in, float* message, float* acc_out, float* topk_score,
                               int64_t* topk_idx, int B, int h0, int w0, int h1, int w1, int H, int Kp, hipStream_t s);
 
+// fine_vreg.hip
+int casmtr_qta_fine_level_vreg(const float* q, const float* key, const float* value, const int64_t* prev_idx, float temp, int topk,
+                               float w_level, const float* acc_in, float* message, float* acc_out, float* topk_score,
+                               int64_t* topk_idx, int B, int h0, int w0, int h1, int w1, int H, int Kp, hipStream_t s);
+
 // =================================================================================================== layout
 // [B,C,HW] -> [B,HW,C] for up to 9 tensors in one launch (a QTAttB call converts 3 pyramids x q,k,v).
 // 64x64 tile through LDS; 16-byte global accesses on both sides (pixels contiguous on the way in, channels on the way out).
@@ -432,13 +437,20 @@ extern "C" int casmtr_qta_fine_level_fwd(const float* q, const float* key, const
                                          int h1, int w1, int H, int D, int Kp, casmtr_stream_t stream) {
     if (D != 32 || (h0 & 1) || (w0 & 1) || (h1 & 1) || (w1 & 1) || topk > 4 * Kp) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
-    // Two kernels, identical results.  Default: the persistent wave-per-(quad, head) LDS-DMA + MFMA kernel (fine_dma.hip) for
-    // 4*Kp <= 64 (measured at 104x104, K = 64, B = 8: 0.28-0.30 ms per launch against 0.335), the round-1 workgroup-per-quad
-    // kernel below otherwise (K = 128 with top-16: 0.21 against 0.25 -- the iterated top-k dominates and four waves share it).
-    // CASMTR_FINE_KERNEL=dma | quad forces one of them (read per call: tests switch it).
+    // Three kernels, identical results.  Default for 4*Kp <= 64 (the finest level of every shipped config): the persistent
+    // wave-per-(quad, head) LDS-DMA + MFMA kernel (fine_dma.hip; 0.29 ms per launch at 104x104, K = 64, B = 8 against 0.335 for
+    // the round-1 kernel); the round-1 workgroup-per-quad kernel below for longer lists (K = 128 with top-16: 0.21 ms against
+    // 0.25 -- the iterated top-k dominates and four waves share it).  fine_vreg.hip (values in registers instead of LDS, 12
+    // instead of 8 waves per CU) measured 0.285 against 0.291 ms and nothing in the whole step: kept selectable, not default.
+    // CASMTR_FINE_KERNEL=vreg | dma | quad forces one of them where the shape allows (read per call: tests switch it).
     {
         const char* ev = getenv("CASMTR_FINE_KERNEL");
-        const bool force_dma = ev && !strcmp(ev, "dma"), force_quad = ev && !strcmp(ev, "quad");
+        const bool force_dma = ev && !strcmp(ev, "dma"), force_quad = ev && !strcmp(ev, "quad"), force_vreg = ev && !strcmp(ev, "vreg");
+        if (force_vreg) {
+            const int r = casmtr_qta_fine_level_vreg(q, key, value, prev_idx, temp, topk, w_level, acc_in, message, acc_out, topk_score,
+                                                     topk_idx, B, h0, w0, h1, w1, H, Kp, (hipStream_t)stream);
+            if (r != CASMTR_ERR_UNSUPPORTED) return r;
+        }
         if (force_dma || (!force_quad && 4 * Kp <= 64)) {
             const int r = casmtr_qta_fine_level_dma(q, key, value, prev_idx, temp, topk, w_level, acc_in, message, acc_out, topk_score,
                                                     topk_idx, B, h0, w0, h1, w1, H, Kp, (hipStream_t)stream);

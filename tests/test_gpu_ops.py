@@ -97,11 +97,11 @@ def _tok(x):
     return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(B, h * w, C))
 
 
-@pytest.mark.parametrize("kernel", ["dma", "quad"])
+@pytest.mark.parametrize("kernel", ["vreg", "dma", "quad"])
 @pytest.mark.parametrize("name", list(CASES["qtattb"]))
 def test_qtattb_levels(ops, monkeypatch, name, kernel):
     """coarse + fine level kernels chained exactly like QTAttB.forward; indices bit-exact vs oracle AND vs the reference."""
-    monkeypatch.setenv("CASMTR_FINE_KERNEL", kernel)   # default persistent LDS-DMA + MFMA kernel | round-1 workgroup-per-quad kernel
+    monkeypatch.setenv("CASMTR_FINE_KERNEL", kernel)   # register-value kernel (lists <= 64) | LDS-DMA kernel | round-1 workgroup-per-quad kernel
     inp = make_inputs("qtattb", name)
     cfg = CASES["qtattb"][name]
     H, topks = cfg["nhead"], cfg["topks"]
@@ -282,10 +282,13 @@ def test_fine_level_wide_candidate_lists(ops, H, Kp, topk):
 
 
 @pytest.mark.parametrize("H,Kp,topk,with_acc", [(8, 16, 8, True), (8, 32, 16, True), (8, 16, 0, True), (4, 32, 16, False), (2, 9, 5, True),
-                                                 (1, 16, 4, True), (4, 5, 20, True)])
-def test_fine_level_dma_kernel_shapes(ops, H, Kp, topk, with_acc):
-    """fine_level_dma_kernel (K = 4*Kp <= 128): every head count / XCD split, ragged candidate counts, top-k == K, no top-k (finest
-    level), no incoming accumulator, query grid != key grid, several pairs -- top-k bit-exact, messages within tolerance"""
+                                                 (1, 16, 4, True), (4, 5, 20, True), (8, 1, 4, True), (2, 13, 0, False)])
+@pytest.mark.parametrize("kernel", ["vreg", "dma"])
+def test_fine_level_dma_kernel_shapes(ops, monkeypatch, kernel, H, Kp, topk, with_acc):
+    """fine_level_vreg_kernel (K = 4*Kp <= 64; longer lists fall through) and fine_level_dma_kernel (K <= 128): every head count /
+    XCD split, ragged candidate counts, top-k == K, no top-k (finest level), no incoming accumulator, query grid != key grid,
+    several pairs -- top-k bit-exact, messages within tolerance"""
+    monkeypatch.setenv("CASMTR_FINE_KERNEL", kernel)
     r = np.random.default_rng(1000 * H + 10 * Kp + topk)
     B, (h0, w0), (h1, w1) = 3, (12, 20), (16, 12)
     C = H * 32
