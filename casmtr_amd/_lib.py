@@ -93,6 +93,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(casmtr_amd has no CPU fallback)")
+        # In a PyTorch process the HIP runtime must be the one torch ships (torch/lib/libamdhip64.so): loading this library first would
+        # bind the process to /opt/rocm's copy of the same SONAME, and torch's streams / allocations then belong to a runtime this
+        # library does not see (every launch fails with hipErrorNoDevice).  The library itself has no torch dependency.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
