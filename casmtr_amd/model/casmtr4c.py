@@ -71,6 +71,19 @@ def _ln(norm, x, residual=None):
     return y if residual is None else residual + y
 
 
+def outdoor_2c_config():
+    """configs/model_configs/outdoor/loftr_ds_quadtree_cas_twins_large_stage4.py: a third stage at 1/2 resolution, NMS there only"""
+    c = outdoor_4c_config()
+    c["coarse2"]["post_config"] = {"method": None}
+    c["coarse3"] = dict(d_model=64, nhead=2, layer_names=["cross", "self", "cross"], window_size=5, attn_window_size=7, dilated=1,
+                        post_config={"method": "maxpool_nms", "window_size": 5})
+    c["match_cascade"].update(border_rm=1, train_pad_num_gt_min=4096)
+    c["match_cascade_2c"] = dict(thr=0.0101, test_thr=0.2, pre_thr=[0.2, 0.2], border_rm=2, double_check=True,
+                                 train_pad_num_gt_min=8192, match_type="softmax", dsmax_temperature=1.0)
+    c["fine_concat_coarse_feat"] = False   # the 1/2-level tokens are the fine features
+    return c
+
+
 # ------------------------------------------------------------------------------------------------------------ backbone
 def _conv_bn(cin, cout, k, stride=1):
     return [nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False), nn.BatchNorm2d(cout)]
@@ -416,25 +429,35 @@ class FineTransformer(nn.Module):
 
 
 class FinePreprocess(nn.Module):   # CascadeFinePreprocess, fine_matching.py:14-67
-    def __init__(self, d_coarse, d_fine, W):
+    def __init__(self, d_coarse, d_fine, W, cat_coarse=True):
         super().__init__()
-        self.W, self.d_fine = W, d_fine
-        self.down_proj = nn.Linear(d_coarse, d_fine)
-        self.merge_feat = nn.Linear(2 * d_fine, d_fine)
+        self.W, self.d_fine, self.cat_coarse = W, d_fine, cat_coarse
+        if cat_coarse:
+            self.down_proj = nn.Linear(d_coarse, d_fine)
+            self.merge_feat = nn.Linear(2 * d_fine, d_fine)
 
-    def forward(self, ff0, ff1, fc0, fc1, st, stride):
-        W = self.W
+    def forward(self, ff0, ff1, fc0, fc1, st, stride, wc0, wc1):
+        """ff*: [B,C,H,W] fine maps; fc*: [B,hw,Cc] tokens of the level the matches live on (None without the concat); wc*: that
+        level's grid width.  The reference unfolds the whole map ([B, C*W*W, L]: 2 x 8.9 GB at 832x832, batch 8, 1/2 level) and
+        then indexes it; here only the matched windows are gathered -- same values, zero padding included."""
+        W, r = self.W, self.W // 2
         b, i, j = st["b_ids"], st["i_ids"], st["j_ids"]
         if b.numel() == 0:
             e = torch.empty(0, W * W, self.d_fine, device=ff0.device)
             return e, e
+        d = torch.arange(-r, r + 1, device=ff0.device)
+        dy, dx = torch.meshgrid(d, d, indexing="ij")
+        dy, dx = dy.reshape(1, -1), dx.reshape(1, -1)
 
-        def windows(f, ids):   # W x W patch of the fine map around every selected 1/4-level token
-            u = F.unfold(f, kernel_size=(W, W), stride=stride, padding=W // 2)            # [B, C*WW, L]
-            u = u.view(f.shape[0], f.shape[1], W * W, -1).permute(0, 3, 2, 1)            # [B, L, WW, C]
-            return u[b, ids]
-        w0, w1 = windows(ff0, i), windows(ff1, j)
-        c = self.down_proj(torch.cat([fc0[b, i], fc1[b, j]], 0))                          # [2n, d_fine]
+        def windows(f, ids, wc):   # W x W patch of the fine map around every selected token (centre = token * stride)
+            fp = F.pad(f, (r, r, r, r)).permute(0, 2, 3, 1)                                   # [B, H+2r, W+2r, C]
+            ys = (torch.div(ids, wc, rounding_mode="trunc") * stride + r)[:, None] + dy
+            xs = ((ids % wc) * stride + r)[:, None] + dx
+            return fp[b[:, None], ys, xs]                                                     # [n, WW, C]
+        w0, w1 = windows(ff0, i, wc0), windows(ff1, j, wc1)
+        if not self.cat_coarse:
+            return w0, w1
+        c = self.down_proj(torch.cat([fc0[b, i], fc1[b, j]], 0))                              # [2n, d_fine]
         m = self.merge_feat(torch.cat([torch.cat([w0, w1], 0), c[:, None, :].expand(-1, W * W, -1)], -1))
         return torch.chunk(m, 2, dim=0)
 
@@ -459,10 +482,15 @@ def fine_matching(f0, f1, st, scale):
 
 # ------------------------------------------------------------------------------------------------------------ the model
 class CasMTR4c(nn.Module):
+    """CasMTR-4c (cascade_model_stage3.py); with config['coarse3'] the 1/2-resolution third stage of CasMTR-2c
+    (cascade_model_stage4.py) is added: up_block2, loftr_coarse_2c, cascade_matching_2c, fine refinement on the 1/2-level tokens."""
+
     def __init__(self, config=None):
         super().__init__()
         c = self.config = config or outdoor_4c_config()
         b, ts = c["block_dims"], c["train_size"]
+        self.has_2c = c.get("coarse3") is not None
+        self.fine_level = "2c" if self.has_2c else "4c"
         self.backbone = TwinsFPN(b)
         self.pos_encoding_8c = SinePositionEncoding(b[2], (ts // 8, ts // 8))
         self.loftr_coarse_8c = CoarseTransformer(c["coarse"])
@@ -470,16 +498,22 @@ class CasMTR4c(nn.Module):
         self.pos_encoding_4c = SinePositionEncoding(b[1], (ts // 4, ts // 4))
         self.up_block1 = UpBlock(b[2], b[1])
         self.loftr_coarse_4c = CascadeTransformer(c["coarse2"])
-        self.cascade_matching_4c = CascadeMatching(c["match_cascade"], {"propagation": "window", "dilated": c["coarse2"].get("dilated", 1),
-                                                                       "post_config": c["coarse2"]["post_config"]}, stage="4c")
-        self.fine_preprocess = FinePreprocess(c["coarse2"]["d_model"], c["fine"]["d_model"], c["fine_window_size"])
+        cas = lambda cc: {"propagation": "window", "dilated": cc.get("dilated", 1), "post_config": cc["post_config"]}
+        self.cascade_matching_4c = CascadeMatching(c["match_cascade"], cas(c["coarse2"]), stage="4c")
+        if self.has_2c:
+            self.pos_encoding_2c = SinePositionEncoding(b[0], (ts // 2, ts // 2))
+            self.up_block2 = UpBlock(b[1], b[0])
+            self.loftr_coarse_2c = CascadeTransformer(c["coarse3"])
+            self.cascade_matching_2c = CascadeMatching(c["match_cascade_2c"], cas(c["coarse3"]), stage="2c")
+        self.fine_preprocess = FinePreprocess(c["coarse2"]["d_model"], c["fine"]["d_model"], c["fine_window_size"],
+                                              c.get("fine_concat_coarse_feat", True))
         self.loftr_fine = FineTransformer(c["fine"])
 
     def load_state_dict(self, state_dict, *args, **kwargs):   # cascade_model_stage3.py:180-184
         sd = {(k[len("matcher."):] if k.startswith("matcher.") else k): v for k, v in state_dict.items()}
         return super().load_state_dict(sd, *args, **kwargs)
 
-    # the forward pass in four pieces (tests drive them one at a time on the reference's stage inputs)
+    # the forward pass in pieces (tests drive them one at a time on the reference's stage inputs)
     def features(self, data):
         """backbone -> (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1); records the grid sizes in data"""
         im0, im1 = data["image0"], data["image1"]
@@ -493,7 +527,8 @@ class CasMTR4c(nn.Module):
             out = tuple(zip(a, b))
         (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1) = out
         data.update(hw0_8c=tuple(f8_0.shape[2:]), hw1_8c=tuple(f8_1.shape[2:]), hw0_4c=tuple(f4_0.shape[2:]),
-                    hw1_4c=tuple(f4_1.shape[2:]), hw0_f=tuple(ff0.shape[2:]), hw1_f=tuple(ff1.shape[2:]))
+                    hw1_4c=tuple(f4_1.shape[2:]), hw0_2c=tuple(ff0.shape[2:]), hw1_2c=tuple(ff1.shape[2:]),
+                    hw0_f=tuple(ff0.shape[2:]), hw1_f=tuple(ff1.shape[2:]))
         return out
 
     def _masks(self, data, level):   # set_stage_mask, cascade_model_stage3.py:60-68
@@ -511,37 +546,51 @@ class CasMTR4c(nn.Module):
         self.coarse_matching_8c(t0.float(), t1.float(), data, mask_c0=m0, mask_c1=m1, level="8c")
         return t0, t1
 
-    def cascade_stage(self, f4_0, f4_1, t8_0, t8_1, data):
-        """1/4: up-sample the 1/8 tokens into the 1/4 features, cascade transformer around the 1/8 argmax, window matching + NMS
-        -> tokens [B, HW, C] x 2; data['stage_4c']"""
-        f4_0 = self.up_block1(f4_0, _grid(t8_0, *data["hw0_8c"]))
-        f4_1 = self.up_block1(f4_1, _grid(t8_1, *data["hw1_8c"]))
-        st8 = data["stage_8c"]
-        t0, t1, idx01, idx10 = self.loftr_coarse_4c(self.pos_encoding_4c(f4_0), self.pos_encoding_4c(f4_1),
-                                                    st8["next_idx_c01"], st8["next_idx_c10"])
-        m0, m1 = self._masks(data, "4c")
-        self.cascade_matching_4c(t0.float(), t1.float(), idx01, idx10, data, mask_c0=m0, mask_c1=m1, level="4c", pre_level="8c")
+    def cascade_stage(self, f_0, f_1, tp_0, tp_1, data, level="4c"):
+        """1/4 (or 1/2): up-sample the previous level's tokens into this level's backbone features, cascade transformer around the
+        previous level's argmax, window matching (+ NMS) -> tokens [B, HW, C] x 2; data['stage_<level>']"""
+        prev, pre_levels = ("8c", "8c") if level == "4c" else ("4c", ["8c", "4c"])
+        up, pe, tr, mt = ((self.up_block1, self.pos_encoding_4c, self.loftr_coarse_4c, self.cascade_matching_4c) if level == "4c" else
+                          (self.up_block2, self.pos_encoding_2c, self.loftr_coarse_2c, self.cascade_matching_2c))
+        f_0 = up(f_0, _grid(tp_0, *data[f"hw0_{prev}"]))
+        f_1 = up(f_1, _grid(tp_1, *data[f"hw1_{prev}"]))
+        stp = data[f"stage_{prev}"]
+        t0, t1, idx01, idx10 = tr(pe(f_0), pe(f_1), stp["next_idx_c01"], stp["next_idx_c10"])
+        m0, m1 = self._masks(data, level)
+        mt(t0.float(), t1.float(), idx01, idx10, data, mask_c0=m0, mask_c1=m1, level=level, pre_level=pre_levels)
         return t0, t1
 
-    def fine_stage(self, ff0, ff1, t4_0, t4_1, data):
-        """1/2: W x W refinement around every 1/4-level match -> data['mkpts0_f' | 'mkpts1_f' | 'expec_f' | 'm_bids']"""
-        st4 = data["stage_4c"]
-        w0, w1 = self.fine_preprocess(ff0, ff1, t4_0, t4_1, st4, data["hw0_f"][0] // data["hw0_4c"][0])
+    def fine_stage(self, ff0, ff1, tc_0, tc_1, data):
+        """W x W refinement around every match of the last cascade level -> data['mkpts0_f' | 'mkpts1_f' | 'expec_f' | 'm_bids'].
+        4c model: windows of the 1/2 backbone map + the projected 1/4 tokens; 2c model: windows of the 1/2-level tokens themselves."""
+        lv = self.fine_level
+        st = data[f"stage_{lv}"]
+        if self.has_2c:
+            ff0, ff1 = _grid(tc_0, *data["hw0_2c"]), _grid(tc_1, *data["hw1_2c"])
+        w0, w1 = self.fine_preprocess(ff0, ff1, tc_0, tc_1, st, data["hw0_f"][0] // data[f"hw0_{lv}"][0], data[f"hw0_{lv}"][1],
+                                      data[f"hw1_{lv}"][1])
         if w0.shape[0]:
             w0, w1 = self.loftr_fine(w0, w1)
         scale = data["hw0_i"][0] / data["hw0_f"][0]
         if "scale0" in data:   # per-pair resize factors of the dataset loaders (fine_matching.py:131)
-            scale = scale * data["scale1"][st4["b_ids"]]
-        mk0, mk1, expec = fine_matching(w0.float(), w1.float(), st4, scale)
-        data.update(mkpts0_f=mk0, mkpts1_f=mk1, expec_f=expec, m_bids=st4["m_bids"])
+            scale = scale * data["scale1"][st["b_ids"]]
+        mk0, mk1, expec = fine_matching(w0.float(), w1.float(), st, scale)
+        data.update(mkpts0_f=mk0, mkpts1_f=mk1, expec_f=expec, m_bids=st["m_bids"])
         return data
 
     @torch.no_grad()
     def forward(self, data):
         """data: {'image0','image1': [N,3,H,W] in [0,1]; optional 'mask0_origin','mask1_origin' [N,H,W] bool, 'scale0','scale1'}.
-        Updated in place with the reference's keys: hw*_i / hw*_8c / hw*_4c / hw*_f, stage_8c, stage_4c, m_bids, mkpts0_f,
-        mkpts1_f, expec_f."""
+        Updated in place with the reference's keys: hw*_i / hw*_8c / hw*_4c / hw*_2c / hw*_f, stage_8c, stage_4c (stage_2c), m_bids,
+        mkpts0_f, mkpts1_f, expec_f."""
         (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1) = self.features(data)
         t8_0, t8_1 = self.coarse_stage(f8_0, f8_1, data)
-        t4_0, t4_1 = self.cascade_stage(f4_0, f4_1, t8_0, t8_1, data)
-        return self.fine_stage(ff0, ff1, t4_0, t4_1, data)
+        t_0, t_1 = self.cascade_stage(f4_0, f4_1, t8_0, t8_1, data, "4c")
+        if self.has_2c:
+            t_0, t_1 = self.cascade_stage(ff0, ff1, t_0, t_1, data, "2c")
+        return self.fine_stage(ff0, ff1, t_0, t_1, data)
+
+
+class CasMTR2c(CasMTR4c):
+    def __init__(self, config=None):
+        super().__init__(config or outdoor_2c_config())

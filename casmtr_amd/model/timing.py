@@ -3,21 +3,23 @@ A SECOND metric next to bench.py's hot-path line -- it includes the torch-op glu
 self-attention) that the hot-path step leaves out.  Used by bench.py ('whole_model' object) and tools/model_e2e_time.py."""
 import torch
 
-from .casmtr4c import CasMTR4c, outdoor_4c_config
+from .casmtr4c import CasMTR4c, outdoor_2c_config, outdoor_4c_config
 
 
-def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda"):
-    cfg = outdoor_4c_config()
+def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda", model="4c"):
+    cfg = outdoor_2c_config() if model == "2c" else outdoor_4c_config()
     if coarse_thr is not None:
         cfg["match_coarse"]["thr"] = coarse_thr
     if cascade_thr is not None:
         cfg["match_cascade"].update(test_thr=cascade_thr, pre_thr=[0.0])
+        if "match_cascade_2c" in cfg:
+            cfg["match_cascade_2c"].update(test_thr=cascade_thr, pre_thr=[0.0, 0.0])
     torch.manual_seed(0)
     m = CasMTR4c(cfg).eval().to(device)
     g = torch.Generator(device=device).manual_seed(1)
     mk = lambda: torch.rand((batch, 3, size, size), device=device, generator=g)
     sets = [(mk(), mk()) for _ in range(2)]
-    names = ["backbone", "stage_8c", "stage_4c", "fine"]
+    names = ["backbone", "stage_8c", "stage_4c"] + (["stage_2c"] if model == "2c" else []) + ["fine"]
     acc = dict.fromkeys(names, 0.0)
     nm = 0
 
@@ -25,17 +27,20 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
         nonlocal nm
         im0, im1 = sets[i % 2]
         data = {"image0": im0, "image1": im1}
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
         with torch.no_grad():
             ev[0].record()
             (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1) = m.features(data)
             ev[1].record()
             t8 = m.coarse_stage(f8_0, f8_1, data)
             ev[2].record()
-            t4 = m.cascade_stage(f4_0, f4_1, *t8, data)
+            t = m.cascade_stage(f4_0, f4_1, *t8, data, "4c")
             ev[3].record()
-            m.fine_stage(ff0, ff1, *t4, data)
-            ev[4].record()
+            if model == "2c":
+                t = m.cascade_stage(ff0, ff1, *t, data, "2c")
+                ev[4].record()
+            m.fine_stage(ff0, ff1, *t, data)
+            ev[-1].record()
         torch.cuda.synchronize()
         if timed:
             for k, n in enumerate(names):
@@ -51,7 +56,7 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / steps
-    out = {"metric": "whole-model image pairs/sec (CasMTR-4c: torch glue + HIP hot path, fp32)", "value": round(batch / ms * 1e3, 2),
+    out = {"metric": f"whole-model image pairs/sec (CasMTR-{model}: torch glue + HIP hot path, fp32)", "value": round(batch / ms * 1e3, 2),
            "unit": "pairs/s", "ms_per_step": round(ms, 2), "batch": batch, "size": size, "steps": steps,
            "stage_ms": {k: round(v / steps, 2) for k, v in acc.items()}, "matches_per_pair": round(nm / steps / batch, 1),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "data": "synthetic", "weights": "random-init"}

@@ -193,3 +193,117 @@ def test_whole_forward(fx):
               and float((mine[(int(a[0]), int(a[1]))] - b).abs().max()) < 0.25)
     assert hit >= 0.9 * len(ref0), f"{hit} of {len(ref0)} reference matches reproduced ({len(mine)} found)"
     assert abs(len(mine) - len(ref0)) <= 0.1 * len(ref0) + 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CasMTR-2c (cascade_model_stage4.py): the third stage at 1/2 resolution, fixture from gen_golden_model.py 2c (256x128)
+FIX2 = os.path.join(HERE, "golden", "model2c_london_bridge.npz")
+
+
+@pytest.fixture(scope="module")
+def fx2():
+    z = np.load(FIX2)
+    return {k: z[k] for k in z.files}
+
+
+def _model2c(fx2, device):
+    from casmtr_amd.model import CasMTR2c, outdoor_2c_config
+    c = outdoor_2c_config()
+    thr = fx2["thresholds"]
+    c["match_coarse"]["thr"] = float(thr[0])
+    c["match_cascade"].update(test_thr=float(thr[1]), pre_thr=[float(thr[2])], double_check=bool(thr[3]))
+    c["match_cascade_2c"].update(test_thr=float(thr[1]), pre_thr=[float(thr[2])] * 2, double_check=bool(thr[3]))
+    m = CasMTR2c(c).eval()
+    sd = m.state_dict()
+    for k, v in model_state({k: tuple(v.shape) for k, v in sd.items()}).items():
+        sd[k] = torch.from_numpy(v)
+    m.load_state_dict(sd)
+    return m.to(device)
+
+
+def test_state_dict_layout_2c_matches_reference():
+    from casmtr_amd.model import CasMTR2c
+    with open(os.path.join(HERE, "golden", "model2c_state_keys.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v.shape) for k, v in CasMTR2c().state_dict().items()}
+    assert sorted(mine) == sorted(ref)
+    assert all(mine[k] == ref[k] for k in ref)
+
+
+def _stage2_from_fixture(fx2, device):
+    t = lambda k, dt=torch.int64: torch.from_numpy(fx2[k].astype(np.int64) if dt == torch.int64 else fx2[k]).to(device).to(dt)
+    return {"b_ids": t("m2_b_ids"), "i_ids": t("m2_i_ids"), "j_ids": t("m2_j_ids"), "m_bids": t("m2_b_ids"),
+            "mconf": t("m2_mconf", torch.float32), "mkpts0_c": t("m2_mkpts0_c", torch.float32), "mkpts1_c": t("m2_mkpts1_c", torch.float32)}
+
+
+def _sizes2(fx2, data):
+    H, W = fx2["image0"].shape[2:]
+    data.update(bs=1, hw0_i=(H, W), hw1_i=(H, W))
+    for lv, d in (("8c", 8), ("4c", 4), ("2c", 2), ("f", 2)):
+        data[f"hw0_{lv}"] = data[f"hw1_{lv}"] = (H // d, W // d)
+    return data
+
+
+def _fine_stage_2c(fx2, device):
+    m = _model2c(fx2, device)
+    data = _sizes2(fx2, {})
+    t2 = torch.from_numpy(fx2["t2"]).to(device).float()
+    data["stage_2c"] = _stage2_from_fixture(fx2, device)
+    with torch.no_grad():
+        m.fine_stage(None, None, t2[:1], t2[1:], data)
+    assert len(fx2["mkpts1_f"]) >= 50
+    _close(data["mkpts0_f"], fx2["mkpts0_f"], 0, "mkpts0_f")
+    _close(data["expec_f"], fx2["expec_f"], 1e-3, "expec_f")
+    assert float((data["mkpts1_f"].cpu() - torch.from_numpy(fx2["mkpts1_f"])).abs().max()) < 5e-3   # pixels
+
+
+def test_fine_stage_2c_cpu(fx2):
+    _fine_stage_2c(fx2, "cpu")
+
+
+@pytest.mark.gpu
+def test_fine_stage_2c_gpu(fx2):
+    _fine_stage_2c(fx2, "cuda")
+
+
+@pytest.mark.gpu
+def test_third_stage_on_reference_tokens(fx2):
+    """up_block2 + the 1/2-level cascade transformer on this model's own 1/2 backbone map and the fixture's fp16-exact 1/4 tokens /
+    1/4 argmax; then the 1/2 matcher (NMS, both previous levels' confidences) on the reference's 1/2 tokens."""
+    m = _model2c(fx2, "cuda")
+    im = [torch.from_numpy(fx2[k]).cuda().float() / 255.0 for k in ("image0", "image1")]
+    data = {"image0": im[0], "image1": im[1]}
+    t4 = torch.from_numpy(fx2["t4"]).cuda().float()
+    idx = lambda k: torch.from_numpy(fx2[k].astype(np.int64)).cuda()
+    cf = lambda k: torch.from_numpy(fx2[k]).cuda()
+    with torch.no_grad():
+        _, _, (ff0, ff1) = m.features(data)
+        data["stage_8c"] = {"next_conf_c01": cf("m8_next_conf_c01"), "next_conf_c01_s": None}
+        data["stage_4c"] = {"next_idx_c01": idx("m4_next_idx_c01"), "next_idx_c10": idx("m4_next_idx_c10"),
+                            "next_conf_c01": cf("m4_next_conf_c01"), "next_conf_c01_s": None}
+        t0, t1 = m.cascade_stage(ff0, ff1, t4[:1], t4[1:], data, "2c")
+    _close(torch.cat([t0, t1]), fx2["t2"].astype(np.float32), 3e-3, "1/2 tokens")
+    from casmtr_amd import ops
+    t2 = torch.from_numpy(fx2["t2"]).cuda().float()
+    H2, W2 = data["hw0_2c"]
+    wi = [ops.WindowIndex(ops.window_warp_idx(data["stage_4c"][k], H2 // 2, W2 // 2, 5), (H2, W2), (H2, W2), 1)
+          for k in ("next_idx_c01", "next_idx_c10")]
+    m.cascade_matching_2c(t2[:1].contiguous(), t2[1:].contiguous(), wi[0], wi[1], data, level="2c", pre_level=["8c", "4c"])
+    s2 = data["stage_2c"]
+    assert len(fx2["m2_i_ids"]) >= 50
+    assert s2["i_ids"].cpu().tolist() == fx2["m2_i_ids"].astype(np.int64).tolist()
+    assert s2["j_ids"].cpu().tolist() == fx2["m2_j_ids"].astype(np.int64).tolist()
+    _close(s2["mconf"], fx2["m2_mconf"], 1e-4, "mconf")
+
+
+@pytest.mark.gpu
+def test_whole_forward_2c(fx2):
+    m = _model2c(fx2, "cuda")
+    im = [torch.from_numpy(fx2[k]).cuda().float() / 255.0 for k in ("image0", "image1")]
+    data = m({"image0": im[0], "image1": im[1]})
+    mine = {(int(a[0]), int(a[1])): b for a, b in zip(data["mkpts0_f"].cpu().tolist(), data["mkpts1_f"].cpu())}
+    ref0, ref1 = fx2["mkpts0_f"], torch.from_numpy(fx2["mkpts1_f"])
+    hit = sum(1 for a, b in zip(ref0.tolist(), ref1) if (int(a[0]), int(a[1])) in mine
+              and float((mine[(int(a[0]), int(a[1]))] - b).abs().max()) < 0.25)
+    assert hit >= 0.9 * len(ref0), f"{hit} of {len(ref0)} reference matches reproduced ({len(mine)} found)"
+    assert abs(len(mine) - len(ref0)) <= 0.1 * len(ref0) + 2

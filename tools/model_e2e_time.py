@@ -19,5 +19,6 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--coarse-thr", type=float, default=None)
     ap.add_argument("--cascade-thr", type=float, default=None)
+    ap.add_argument("--model", choices=["4c", "2c"], default="4c")
     a = ap.parse_args()
-    print(json.dumps(time_whole_model(a.batch, a.size, a.steps, a.warmup, a.coarse_thr, a.cascade_thr)))
+    print(json.dumps(time_whole_model(a.batch, a.size, a.steps, a.warmup, a.coarse_thr, a.cascade_thr, model=a.model)))
