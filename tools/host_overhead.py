@@ -1,40 +1,45 @@
-"""Host-side cost of one hot-path step: enqueue time (no sync) vs GPU time, with / without the HIP-event hooks and the
-match gather, + optional cProfile of the enqueue (--cprofile)."""
-import cProfile, pstats, sys, time, io
-import torch
+#!/usr/bin/env python3
+"""How long the host needs to enqueue one hot-path step (no device sync inside), next to the device time of the step:
+if the first is not well below the second, launch gaps open whenever the host is slow or shared."""
+import json
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from casmtr_amd import _lib, dist as cdist
-from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
+import sys
+import time
 
-callers = "--with-callers" in sys.argv
-cfg = HotPathConfig(callers=callers)
-dev = torch.device("cuda", 0)
-model = HotPath(cfg).to(dev)
-inp = make_synthetic_inputs(cfg, 8, dev, seed=1)
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs  # noqa: E402
+
+from casmtr_amd.matching.cascade_matching import CascadeMatching  # noqa: E402
+
+stamp = []
+_orig = CascadeMatching.finalize.__func__
+
+
+def _fin(cls, data, level):   # the first finalize() of a step = the point where everything has been enqueued
+    stamp.append(time.perf_counter())
+    return _orig(cls, data, level)
+
+
+CascadeMatching.finalize = classmethod(_fin)
+cfg = HotPathConfig.named(sys.argv[1] if len(sys.argv) > 1 else "4c")
+model = HotPath(cfg).cuda()
+inp = make_synthetic_inputs(cfg, 8, "cuda", seed=1)
 for _ in range(3):
-    model(inp)
-torch.cuda.synchronize()
-for prof, gather in ((False, False), (True, False), (False, True), (True, True), (False, False)):
-    _lib.prof_enable(prof)
-    ts = []
-    for rep in range(6):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out = model(inp)
-        if gather:
-            cdist.gather_matches(out, pairs_per_rank=8)
-        t1 = time.perf_counter()
-        torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) * 1e3)
-    _lib.prof_enable(False)
-    print(f"prof={prof} gather={gather}: step ms {['%.2f' % t for t in ts]}")
-if "--cprofile" in sys.argv:
-    pr = cProfile.Profile()
-    pr.enable()
     out = model(inp)
-    pr.disable()
+torch.cuda.synchronize()
+enq, tot = [], []
+for _ in range(10):
     torch.cuda.synchronize()
-    s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(35)
-    print(s.getvalue()[:6000])
+    stamp.clear()
+    t0 = time.perf_counter()
+    out = model(inp)
+    t1 = stamp[0]
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3)
+    tot.append((t2 - t0) * 1e3)
+enq.sort(); tot.sort()
+print(json.dumps({"config": cfg.name, "host_enqueue_ms_median": round(enq[5], 2), "host_enqueue_ms_max": round(enq[-1], 2),
+                  "step_ms_median": round(tot[5], 2)}))
