@@ -63,6 +63,12 @@ def _lin(layer, x):
     return layer(x)
 
 
+def _swap_halves(t):
+    """[2B, ...] -> the two halves of the batch exchanged (image 0 <-> image 1 of every pair)"""
+    B = t.shape[0] // 2
+    return torch.cat([t[B:], t[:B]])
+
+
 def _ln(norm, x, residual=None):
     """norm(x) (+ residual)"""
     if _fast(x) and x.shape[-1] % 4 == 0:
@@ -314,9 +320,12 @@ class QuadtreeBlock(nn.Module):   # transformer.py:141-196
         self.attn = QuadtreeAttention(dim, num_heads=heads, topks=topks, scale=3, attn_type="B")
         self.mlp = _ConvMlp(dim, 4 * dim)
 
-    def forward(self, x, target, H, W, H1, W1):
+    def forward(self, x, target, H, W, H1, W1, swap=False):
+        """swap: x holds both images of every pair ([2B,N,C], image 0 first) and the target is the other half -- one launch per
+        layer for both directions; norm1(target) is then the swapped norm1(x)"""
         xn = _ln(self.norm1, x)
-        x = x + self.attn(xn, xn if target is x else _ln(self.norm1, target), H, W, H1, W1)
+        tn = _swap_halves(xn) if swap else (xn if target is x else _ln(self.norm1, target))
+        x = x + self.attn(xn, tn, H, W, H1, W1)
         return x + self.mlp(_ln(self.norm2, x), H, W)
 
 
@@ -327,8 +336,9 @@ class CascadeQuadtreeBlock(nn.Module):   # transformer.py:305-345
         self.attn = CascadeQuadtreeAttention(dim, num_heads=heads, scale=2, dilated=dilated)
         self.mlp = _ConvMlp(dim, 4 * dim)
 
-    def forward(self, x, target, H, W, H1, W1, idx):
-        y, _ = self.attn(_ln(self.norm1, x), _ln(self.norm1, target), H, W, H1, W1, idx, None, want_idx=False)
+    def forward(self, x, target, H, W, H1, W1, idx, swap=False):
+        xn = _ln(self.norm1, x)
+        y, _ = self.attn(xn, _swap_halves(xn) if swap else _ln(self.norm1, target), H, W, H1, W1, idx, None, want_idx=False)
         x = x + y
         return x + self.mlp(_ln(self.norm2, x), H, W)
 
@@ -350,6 +360,12 @@ class CoarseTransformer(nn.Module):   # LocalFeatureTransformer, block_type 'qua
 
     def forward(self, f0, f1):
         (H0, W0), (H1, W1) = f0.shape[2:], f1.shape[2:]
+        if f0.shape == f1.shape:   # both images of the pairs in one batch: half the launches, same arithmetic per image
+            B = f0.shape[0]
+            x = torch.cat([_tokens(f0), _tokens(f1)])
+            for layer, name in zip(self.layers, self.layer_names):
+                x = layer(x, x, H0, W0, H0, W0, swap=(name != "self"))
+            return x[:B], x[B:]
         f0, f1 = _tokens(f0).contiguous(), _tokens(f1).contiguous()
         for layer, name in zip(self.layers, self.layer_names):
             if name == "self":
@@ -375,6 +391,13 @@ class CascadeTransformer(nn.Module):   # CascadeFeatureTransformer, 'window' pro
         f0, f1 = _tokens(f0).contiguous(), _tokens(f1).contiguous()
         tp01 = ops.window_warp_idx(next_idx_c01.contiguous(), H0 // 2, W0 // 2, self.ws)   # get_window_warp_idx, :416-440
         tp10 = ops.window_warp_idx(next_idx_c10.contiguous(), H1 // 2, W1 // 2, self.ws)
+        if f0.shape == f1.shape:   # both directions per launch
+            B = f0.shape[0]
+            x, tp = torch.cat([f0, f1]), torch.cat([tp01, tp10])
+            for layer, name in zip(self.layers, self.layer_names):
+                x = layer(x, H0, W0) if name == "self" else layer(x, x, H0, W0, H0, W0, tp, swap=True)
+            return (x[:B], x[B:], ops.WindowIndex(tp01, (H0, W0), (H1, W1), self.dilated),
+                    ops.WindowIndex(tp10, (H1, W1), (H0, W0), self.dilated))
         for layer, name in zip(self.layers, self.layer_names):
             if name == "self":
                 f0, f1 = layer(f0, H0, W0), layer(f1, H1, W1)
