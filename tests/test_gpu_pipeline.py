@@ -339,3 +339,82 @@ def test_qtatt_variants_vs_reference(name):
             out = m(qs, ks, vs, topk_pos=T(inp["topk_pos"]))
     assert out.shape == g["final"].shape
     assert_close(N(out), g["final"], TOL, f"{cfg['kind']} final message vs reference python")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE's full size (832x832, batch of 8): no oracle needed, so the whole batch is covered
+def _snapshot(out):
+    """every tensor the step produces, flattened into {name: tensor}"""
+    snap = {f"message{i}": m for i, m in enumerate(out["messages"])}
+    for lvl in ("8c", "4c"):
+        st = out["data"][f"stage_{lvl}"]
+        for k in ("next_idx_c01", "next_idx_c10", "next_conf_c01", "next_conf_c10", "b_ids", "i_ids", "j_ids", "mconf"):
+            if torch.is_tensor(st.get(k)):
+                snap[f"{lvl}.{k}"] = st[k]
+    return snap
+
+
+def _run_full(cfg_kw=None, B=8, seed=11, env=None, monkeypatch=None, select=None):
+    from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    cfg = HotPathConfig(**(cfg_kw or {}))
+    model = HotPath(cfg).to(DEV)
+    inp = make_synthetic_inputs(cfg, 8, DEV, seed=seed)
+    if select is not None:   # a sub-batch of the same pairs
+        inp = {k: (_take(v, select)) for k, v in inp.items()}
+    with torch.no_grad():
+        model.qta.weight.copy_(inp["weight"])
+        out = model(inp)
+    torch.cuda.synchronize()
+    return _snapshot(out)
+
+
+def _take(v, sel):
+    if torch.is_tensor(v):
+        return v[sel].contiguous() if v.dim() > 1 and v.shape[0] == 8 else v
+    if isinstance(v, (list, tuple)):
+        return [_take(x, sel) for x in v]
+    return v
+
+
+def test_full_size_run_to_run_determinism():
+    """the persistent kernels hand out work dynamically (cursor per wave, XCD-chunked lists): two runs on the same inputs must
+    still agree bit for bit in every output, values included"""
+    a, b = _run_full(), _run_full()
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k} differs between two identical runs"
+
+
+def test_full_size_pairs_are_independent_of_their_batch():
+    """a pair's results do not depend on which other pairs share its launch: pairs 5 and 2 run alone (in that order) give the
+    rows they get inside the batch of 8 -- every message, every argmax, every confidence, bit for bit"""
+    full = _run_full()
+    sel = torch.tensor([5, 2], device=DEV)
+    sub = _run_full(select=sel)
+    for k, v in sub.items():
+        if k.endswith(("b_ids", "i_ids", "j_ids", "mconf")):
+            continue   # match lists are compacted over the batch; compared below per pair
+        assert torch.equal(v, full[k][sel]), f"{k}: pair results depend on the batch"
+    for lvl in ("8c", "4c"):
+        for new_b, old_b in enumerate((5, 2)):
+            m_sub = sub[f"{lvl}.b_ids"] == new_b
+            m_full = full[f"{lvl}.b_ids"] == old_b
+            for k in ("i_ids", "j_ids", "mconf"):
+                assert torch.equal(sub[f"{lvl}.{k}"][m_sub], full[f"{lvl}.{k}"][m_full]), f"{lvl}.{k} of pair {old_b}"
+
+
+@pytest.mark.parametrize("env", [{"CASMTR_FINE_KERNEL": "quad"}, {"CASMTR_FINE_KERNEL": "vreg"}, {"CASMTR_CASCADE_KERNEL": "quad"},
+                                 {"CASMTR_WINDOW_KERNEL": "quad"}, {"CASMTR_COARSE_KERNEL": "fused"}],
+                         ids=lambda e: "-".join(f"{k[7:].lower()}={v}" for k, v in e.items()))
+def test_full_size_kernel_variants_agree(monkeypatch, env):
+    """every alternative kernel behind the CASMTR_*_KERNEL selectors reproduces the default kernels' indices exactly and their
+    values within the softmax tolerance, on the whole full-size batch"""
+    ref = _run_full()
+    alt = _run_full(env=env, monkeypatch=monkeypatch)
+    for k in ref:
+        if ref[k].dtype in (torch.int64, torch.int32, torch.bool):
+            assert torch.equal(ref[k], alt[k]), f"{k}: index output differs under {env}"
+        else:
+            assert ref[k].shape == alt[k].shape and float((ref[k] - alt[k]).abs().max()) <= TOL, f"{k} under {env}"
