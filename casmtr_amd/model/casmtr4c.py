@@ -41,6 +41,20 @@ def outdoor_4c_config():
                            match_type="softmax", dsmax_temperature=1.0))
 
 
+# Optional reduced precision for the CONVOLUTIONS of the glue (backbone, patch embeddings, up-sampling blocks): the reference's
+# test.py evaluates under fp16 autocast (pl.Trainer(precision=16), lightning_cascade.py:352).  Attention, matching, LayerNorm and
+# the token GEMMs stay fp32; convolution outputs are cast back to fp32.  Off by default (parity tests run fp32 throughout).
+_CONV_DTYPE = [None]
+
+
+def _cv(module, x):
+    dt = _CONV_DTYPE[0]
+    if dt is None or not x.is_cuda:
+        return module(x)
+    with torch.autocast("cuda", dtype=dt):
+        return module(x).float()
+
+
 def _fast(x):
     """inference on the GPU: the token-major HIP element kernels apply (otherwise the same arithmetic on torch ops)"""
     return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
@@ -117,7 +131,7 @@ class _PatchEmbed(nn.Module):   # gvt.py:256-281
 
     def forward(self, x):
         H, W = x.shape[2] // self.patch, x.shape[3] // self.patch
-        return _ln(self.norm, _tokens(self.proj(x))), (H, W)
+        return _ln(self.norm, _tokens(_cv(self.proj, x))), (H, W)
 
 
 class _PosCNN(nn.Module):   # gvt.py:397-411, stride 1
@@ -193,7 +207,7 @@ class _ReducedAttention(nn.Module):
         B, N, C = x.shape
         nh = self.heads
         q = _lin(self.q, x).reshape(B, N, nh, C // nh).permute(0, 2, 1, 3)
-        r = _ln(self.norm, _tokens(self.sr(_grid(x, H, W))))
+        r = _ln(self.norm, _tokens(_cv(self.sr, _grid(x, H, W))))
         kv = self.kv(r).reshape(B, -1, 2, nh, C // nh).permute(2, 0, 3, 1, 4)
         # softmax(q k^T * scale) v without the [B, heads, N, N/sr^2] matrix in HBM (7.5 GB at 832x832, batch 8)
         o = F.scaled_dot_product_attention(q, kv[0], kv[1], scale=self.scale)
@@ -261,12 +275,12 @@ class TwinsFPN(nn.Module):   # twins_fpn.py:75-180 -> [1/8 (C=256), 1/4 (C=128),
         mean = x.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
         std = x.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
         x = ((x - mean) / std).contiguous(memory_format=torch.channels_last)
-        x1 = self.layer1(self.conv1(x))
+        x1 = _cv(nn.Sequential(self.conv1, self.layer1), x)
         x2, x3 = self.vit.forward_features(x)
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="bilinear", align_corners=True)
-        x3o = self.layer3_outconv(x3)
-        x2o = self.layer2_outconv2(self.layer2_outconv(x2) + up(x3o))
-        x1o = self.layer1_outconv2(self.layer1_outconv(x1) + up(x2o))
+        x3o = _cv(self.layer3_outconv, x3)
+        x2o = _cv(self.layer2_outconv2, _cv(self.layer2_outconv, x2) + up(x3o))
+        x1o = _cv(self.layer1_outconv2, _cv(self.layer1_outconv, x1) + up(x2o))
         return x3o, x2o, x1o
 
 
@@ -414,7 +428,7 @@ class UpBlock(nn.Module):   # cascade_model_stage3.py:25-47
         self.up = nn.Sequential(nn.Conv2d(dim2, dim2, 3, padding=1, bias=False), nn.BatchNorm2d(dim2), nn.LeakyReLU())
 
     def forward(self, fine, coarse):
-        return self.up(fine + self.inner(F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True)))
+        return _cv(self.up, fine + _cv(self.inner, F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True)))
 
 
 # ------------------------------------------------------------------------------------------------------------ fine level
@@ -508,9 +522,11 @@ class CasMTR4c(nn.Module):
     """CasMTR-4c (cascade_model_stage3.py); with config['coarse3'] the 1/2-resolution third stage of CasMTR-2c
     (cascade_model_stage4.py) is added: up_block2, loftr_coarse_2c, cascade_matching_2c, fine refinement on the 1/2-level tokens."""
 
-    def __init__(self, config=None):
+    def __init__(self, config=None, conv_dtype=None):
+        """conv_dtype: None (fp32 everywhere) | torch.float16 | torch.bfloat16 for the glue's convolutions (see _cv)"""
         super().__init__()
         c = self.config = config or outdoor_4c_config()
+        self.conv_dtype = conv_dtype
         b, ts = c["block_dims"], c["train_size"]
         self.has_2c = c.get("coarse3") is not None
         self.fine_level = "2c" if self.has_2c else "4c"
@@ -606,14 +622,21 @@ class CasMTR4c(nn.Module):
         """data: {'image0','image1': [N,3,H,W] in [0,1]; optional 'mask0_origin','mask1_origin' [N,H,W] bool, 'scale0','scale1'}.
         Updated in place with the reference's keys: hw*_i / hw*_8c / hw*_4c / hw*_2c / hw*_f, stage_8c, stage_4c (stage_2c), m_bids,
         mkpts0_f, mkpts1_f, expec_f."""
-        (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1) = self.features(data)
-        t8_0, t8_1 = self.coarse_stage(f8_0, f8_1, data)
-        t_0, t_1 = self.cascade_stage(f4_0, f4_1, t8_0, t8_1, data, "4c")
-        if self.has_2c:
-            t_0, t_1 = self.cascade_stage(ff0, ff1, t_0, t_1, data, "2c")
-        return self.fine_stage(ff0, ff1, t_0, t_1, data)
+        H, W = data["image0"].shape[2:]
+        if H % 32 or W % 32 or data["image1"].shape[2] % 32 or data["image1"].shape[3] % 32:
+            raise ValueError("image sides must be multiples of 32 (three 2x2 quadtree levels below the 1/8 grid), as in the reference")
+        _CONV_DTYPE[0] = self.conv_dtype
+        try:
+            (f8_0, f8_1), (f4_0, f4_1), (ff0, ff1) = self.features(data)
+            t8_0, t8_1 = self.coarse_stage(f8_0, f8_1, data)
+            t_0, t_1 = self.cascade_stage(f4_0, f4_1, t8_0, t8_1, data, "4c")
+            if self.has_2c:
+                t_0, t_1 = self.cascade_stage(ff0, ff1, t_0, t_1, data, "2c")
+            return self.fine_stage(ff0, ff1, t_0, t_1, data)
+        finally:
+            _CONV_DTYPE[0] = None
 
 
 class CasMTR2c(CasMTR4c):
-    def __init__(self, config=None):
-        super().__init__(config or outdoor_2c_config())
+    def __init__(self, config=None, conv_dtype=None):
+        super().__init__(config or outdoor_2c_config(), conv_dtype)

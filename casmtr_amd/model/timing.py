@@ -6,7 +6,7 @@ import torch
 from .casmtr4c import CasMTR4c, outdoor_2c_config, outdoor_4c_config
 
 
-def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda", model="4c"):
+def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda", model="4c", conv_dtype=None):
     cfg = outdoor_2c_config() if model == "2c" else outdoor_4c_config()
     if coarse_thr is not None:
         cfg["match_coarse"]["thr"] = coarse_thr
@@ -15,7 +15,7 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
         if "match_cascade_2c" in cfg:
             cfg["match_cascade_2c"].update(test_thr=cascade_thr, pre_thr=[0.0, 0.0])
     torch.manual_seed(0)
-    m = CasMTR4c(cfg).eval().to(device)
+    m = CasMTR4c(cfg, conv_dtype=conv_dtype).eval().to(device)
     g = torch.Generator(device=device).manual_seed(1)
     mk = lambda: torch.rand((batch, 3, size, size), device=device, generator=g)
     sets = [(mk(), mk()) for _ in range(2)]
@@ -23,8 +23,11 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
     acc = dict.fromkeys(names, 0.0)
     nm = 0
 
+    from . import casmtr4c as _mod
+
     def step(i, timed):
         nonlocal nm
+        _mod._CONV_DTYPE[0] = conv_dtype   # the staged calls below bypass forward(), which normally sets it
         im0, im1 = sets[i % 2]
         data = {"image0": im0, "image1": im1}
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
@@ -56,10 +59,12 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / steps
-    out = {"metric": f"whole-model image pairs/sec (CasMTR-{model}: torch glue + HIP hot path, fp32)", "value": round(batch / ms * 1e3, 2),
+    out = {"metric": f"whole-model image pairs/sec (CasMTR-{model}: torch glue + HIP hot path; attention / matching fp32)", "value": round(batch / ms * 1e3, 2),
            "unit": "pairs/s", "ms_per_step": round(ms, 2), "batch": batch, "size": size, "steps": steps,
            "stage_ms": {k: round(v / steps, 2) for k, v in acc.items()}, "matches_per_pair": round(nm / steps / batch, 1),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "data": "synthetic", "weights": "random-init"}
+    _mod._CONV_DTYPE[0] = None
+    out["conv_dtype"] = "fp32" if conv_dtype is None else str(conv_dtype).replace("torch.", "")
     del m, sets
     torch.cuda.empty_cache()
     return out

@@ -307,3 +307,30 @@ def test_whole_forward_2c(fx2):
               and float((mine[(int(a[0]), int(a[1]))] - b).abs().max()) < 0.25)
     assert hit >= 0.9 * len(ref0), f"{hit} of {len(ref0)} reference matches reproduced ({len(mine)} found)"
     assert abs(len(mine) - len(ref0)) <= 0.1 * len(ref0) + 2
+
+
+@pytest.mark.gpu
+def test_reduced_precision_convolutions(fx):
+    """conv_dtype=torch.float16 (the reference's test.py evaluates under fp16 autocast): only the glue's convolutions change
+    precision; features stay within fp16 round-off of the fp32 model and the forward pass runs end to end"""
+    m = _model(fx, "cuda")
+    im0, im1 = _images(fx, "cuda")
+    with torch.no_grad():
+        ref = m.features({"image0": im0, "image1": im1})
+        from casmtr_amd.model import casmtr4c as mod
+        mod._CONV_DTYPE[0] = torch.float16
+        try:
+            got = m.features({"image0": im0, "image1": im1})
+        finally:
+            mod._CONV_DTYPE[0] = None
+    for (a0, a1), (b0, b1) in zip(ref, got):
+        for a, b in ((a0, b0), (a1, b1)):
+            assert b.dtype == torch.float32
+            rel = float((a - b).abs().max() / a.abs().max())
+            assert 0 < rel < 2e-2, rel
+    m.conv_dtype = torch.float16
+    out = m({"image0": im0, "image1": im1})
+    assert out["mkpts0_f"].shape == out["mkpts1_f"].shape and out["mkpts0_f"].shape[1] == 2
+    assert mod._CONV_DTYPE[0] is None
+    with pytest.raises(ValueError):
+        m({"image0": im0[..., :100], "image1": im1[..., :100]})

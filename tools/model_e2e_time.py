@@ -8,6 +8,8 @@ import json
 import os
 import sys
 
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from casmtr_amd.model.timing import time_whole_model  # noqa: E402
 
@@ -20,5 +22,7 @@ if __name__ == "__main__":
     ap.add_argument("--coarse-thr", type=float, default=None)
     ap.add_argument("--cascade-thr", type=float, default=None)
     ap.add_argument("--model", choices=["4c", "2c"], default="4c")
+    ap.add_argument("--conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32")
     a = ap.parse_args()
-    print(json.dumps(time_whole_model(a.batch, a.size, a.steps, a.warmup, a.coarse_thr, a.cascade_thr, model=a.model)))
+    print(json.dumps(time_whole_model(a.batch, a.size, a.steps, a.warmup, a.coarse_thr, a.cascade_thr, model=a.model,
+                                      conv_dtype={"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}[a.conv_dtype])))
