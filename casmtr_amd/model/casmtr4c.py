@@ -41,9 +41,10 @@ def outdoor_4c_config():
                            match_type="softmax", dsmax_temperature=1.0))
 
 
-# Optional reduced precision for the CONVOLUTIONS of the glue (backbone, patch embeddings, up-sampling blocks): the reference's
-# test.py evaluates under fp16 autocast (pl.Trainer(precision=16), lightning_cascade.py:352).  Attention, matching, LayerNorm and
-# the token GEMMs stay fp32; convolution outputs are cast back to fp32.  Off by default (parity tests run fp32 throughout).
+# Optional reduced precision for the glue's CONVOLUTIONS (backbone, patch embeddings, up-sampling blocks) and MLP / local-attention
+# GEMMs: the reference's test.py evaluates under fp16 autocast (pl.Trainer(precision=16), lightning_cascade.py:352).  QuadTree /
+# cascade attention with their q/k/v projections, the matchers, LayerNorm and softmax stay fp32; outputs are cast back to fp32.
+# Off by default (parity tests run fp32 throughout).
 _CONV_DTYPE = [None]
 
 
@@ -71,7 +72,11 @@ def _grid(t, H, W):
 
 
 def _lin(layer, x):
-    """nn.Linear on tokens: the package's fp32-MFMA NT GEMM (bias in the epilogue) for the big token matrices"""
+    """nn.Linear on tokens: the package's fp32-MFMA NT GEMM (bias in the epilogue) for the big token matrices; with a reduced
+    glue precision (see _cv) the MLP / local-attention GEMMs run in it, as nn.Linear does under the reference's autocast"""
+    dt = _CONV_DTYPE[0]
+    if dt is not None and x.is_cuda:
+        return F.linear(x.to(dt), layer.weight.to(dt), None if layer.bias is None else layer.bias.to(dt)).float()
     if _fast(x) and x.shape[-1] % 32 == 0 and x.numel() // x.shape[-1] >= 4096:
         return ops.linear(x.contiguous(), layer.weight, layer.bias)
     return layer(x)
