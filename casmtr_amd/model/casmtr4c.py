@@ -355,9 +355,9 @@ class CascadeQuadtreeBlock(nn.Module):   # transformer.py:305-345
         self.attn = CascadeQuadtreeAttention(dim, num_heads=heads, scale=2, dilated=dilated)
         self.mlp = _ConvMlp(dim, 4 * dim)
 
-    def forward(self, x, target, H, W, H1, W1, idx, swap=False):
+    def forward(self, x, target, H, W, H1, W1, idx, swap=False, rel_pos=None):
         xn = _ln(self.norm1, x)
-        y, _ = self.attn(xn, _swap_halves(xn) if swap else _ln(self.norm1, target), H, W, H1, W1, idx, None, want_idx=False)
+        y, _ = self.attn(xn, _swap_halves(xn) if swap else _ln(self.norm1, target), H, W, H1, W1, idx, rel_pos, want_idx=False)
         x = x + y
         return x + self.mlp(_ln(self.norm2, x), H, W)
 

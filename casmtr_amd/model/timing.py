@@ -7,6 +7,8 @@ from .casmtr4c import CasMTR4c, outdoor_2c_config, outdoor_4c_config
 
 
 def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda", model="4c", conv_dtype=None):
+    if model == "indoor":
+        return _time_indoor(batch, steps, warmup, conv_dtype, device)
     cfg = outdoor_2c_config() if model == "2c" else outdoor_4c_config()
     if coarse_thr is not None:
         cfg["match_coarse"]["thr"] = coarse_thr
@@ -65,6 +67,60 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "data": "synthetic", "weights": "random-init"}
     _mod._CONV_DTYPE[0] = None
     out["conv_dtype"] = "fp32" if conv_dtype is None else str(conv_dtype).replace("torch.", "")
+    del m, sets
+    torch.cuda.empty_cache()
+    return out
+
+
+def _time_indoor(batch, steps, warmup, conv_dtype, device):
+    """CasMTRIndoor4c on 640x480 frames (BASELINE configs[4] shapes)"""
+    from . import casmtr4c as _mod
+    from .indoor import CasMTRIndoor4c
+    torch.manual_seed(0)
+    m = CasMTRIndoor4c(conv_dtype=conv_dtype).eval().to(device)
+    g = torch.Generator(device=device).manual_seed(1)
+    mk = lambda: torch.rand((batch, 3, 480, 640), device=device, generator=g)
+    sets = [(mk(), mk()) for _ in range(2)]
+    names = ["backbone", "stage_8c", "stage_4c", "fine"]
+    acc = dict.fromkeys(names, 0.0)
+    nm = 0
+
+    def step(i, timed):
+        nonlocal nm
+        _mod._CONV_DTYPE[0] = conv_dtype
+        data = {"image0": sets[i % 2][0], "image1": sets[i % 2][1]}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        with torch.no_grad():
+            ev[0].record()
+            x, f8, f4, ff = m.features(data)
+            ev[1].record()
+            t8 = m.coarse_stage(f8, data)
+            ev[2].record()
+            t4_0, t4_1, ff0, ff1 = m.cascade_stage(x, f4, ff, *t8, data)
+            ev[3].record()
+            m.fine_stage(ff0, ff1, t4_0, t4_1, data)
+            ev[4].record()
+        torch.cuda.synchronize()
+        if timed:
+            for k, n in enumerate(names):
+                acc[n] += ev[k].elapsed_time(ev[k + 1])
+            nm += int(data["mkpts0_f"].shape[0])
+
+    for i in range(warmup):
+        step(i, False)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for i in range(steps):
+        step(i, True)
+    t1.record()
+    torch.cuda.synchronize()
+    _mod._CONV_DTYPE[0] = None
+    ms = t0.elapsed_time(t1) / steps
+    out = {"metric": "whole-model image pairs/sec (CasMTR indoor 4c, 640x480: torch glue + HIP hot path; attention / matching fp32)",
+           "value": round(batch / ms * 1e3, 2), "unit": "pairs/s", "ms_per_step": round(ms, 2), "batch": batch, "size": "640x480",
+           "steps": steps, "stage_ms": {k: round(v / steps, 2) for k, v in acc.items()}, "matches_per_pair": round(nm / steps / batch, 1),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "data": "synthetic", "weights": "random-init",
+           "conv_dtype": "fp32" if conv_dtype is None else str(conv_dtype).replace("torch.", "")}
     del m, sets
     torch.cuda.empty_cache()
     return out

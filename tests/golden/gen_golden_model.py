@@ -172,8 +172,78 @@ def main_2c():
           f"|t2| {float(t2_0.abs().mean()):.3f}; expec std {float(data['expec_f'][:, :2].std()) if len(data['expec_f']) else -1:.3f}")
 
 
+def main_indoor():
+    """the indoor model (cascade_quadtree_stage3.py, indoor stage-3 config): ResNet-FPN + ladder, 8 QuadTree layers with top-k
+    [32,16,16], POLA self-attention, cascade cross-attention with the learned relative position bias, no NMS.  256x128."""
+    ref_stubs.install_full_model_extras()
+    from configs.default import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(REF, "configs/model_configs/indoor/loftr_ds_quadtree_cas_stage3.py"))
+    mc = ref_stubs.lower(cfg)["loftr"]
+    mc["match_coarse"]["thr"] = THRESHOLDS["coarse_thr"]
+    mc["match_cascade"]["test_thr"] = [THRESHOLDS["cascade_thr"]]
+    mc["match_cascade"]["pre_thr"] = [[THRESHOLDS["pre_thr"]] * 2]
+    mc["match_cascade"]["double_check"] = [THRESHOLDS["double_check"]]
+    from src.model.cascade_quadtree_stage3 import CasMTR
+    model = CasMTR(config=mc).eval()
+    sd = model.state_dict()
+    for k, v in model_state({k: tuple(v.shape) for k, v in sd.items()}).items():
+        if sd[k].dtype == torch.float32:      # buffers of integer type (relative_position_index) keep their constructor values
+            sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    import json
+    with open(os.path.join(HERE, "model_indoor_state_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in sd.items()}, f, indent=0)
+    im0, im1 = ge.load_pair(hw=(128, 256))
+    u8 = [(x * 255.0).round().to(torch.uint8) for x in (im0, im1)]
+    im0, im1 = [x.float() / 255.0 for x in u8]
+    x = torch.cat([im0, im1], 0)
+    data = {"image0": im0, "image1": im1, "bs": 1, "hw0_i": im0.shape[2:], "hw1_i": im1.shape[2:]}
+    out = {"image0": u8[0], "image1": u8[1]}
+    with torch.no_grad():
+        f8, f4, ff = model.backbone(x)
+        for lv, f in (("c", f8), ("8c", f8), ("4c", f4), ("2c", ff), ("f", ff)):
+            data[f"hw0_{lv}"] = data[f"hw1_{lv}"] = f.shape[2:]
+        out.update(bb_f8_sub=f8[:, ::4, ::2, ::2].contiguous(), bb_f4_sub=f4[:, ::4, ::2, ::2].contiguous(), bb_ff_sub=ff[:, ::4, ::4, ::4].contiguous())
+        f8r = h16(f8)
+        out["f8"] = f8r.half()
+        t8_0, t8_1 = model.loftr_coarse.forward(model.pos_encoding(f8r[:1]), model.pos_encoding(f8r[1:]), None, None)
+        t8_0, t8_1 = h16(t8_0), h16(t8_1)
+        out["t8"] = torch.cat([t8_0, t8_1]).half()
+        model.coarse_matching.forward(t8_0, t8_1, data, mask_c0=None, mask_c1=None, level="8c")
+        s8 = data["stage_8c"]
+        out.update(m8_next_idx_c01=s8["next_idx_c01"].to(torch.int16), m8_next_idx_c10=s8["next_idx_c10"].to(torch.int16),
+                   m8_next_conf_c01=s8["next_conf_c01"])
+        l4, lf = model.ladder.forward(x, [f4, ff])
+        out.update(lad_4_sub=l4[:, ::4, ::2, ::2].contiguous(), lad_f_sub=lf[:, ::4, ::4, ::4].contiguous())
+        g = lambda t, f: t.transpose(1, 2).reshape(1, -1, *f.shape[2:])
+        f4_0, f4_1 = model.up_block1.forward(l4[:1], l4[1:], g(t8_0, f8), g(t8_1, f8), data["hw0_4c"], data["hw1_4c"], 1)
+        t4_0, t4_1, i01, i10, _ = model.loftr_coarse_4c.forward(model.pos_encoding_4c(f4_0), model.pos_encoding_4c(f4_1),
+                                                                s8["next_idx_c01"], s8["next_idx_c10"], data=data)
+        t4_0, t4_1 = h16(t4_0), h16(t4_1)
+        out["t4"] = torch.cat([t4_0, t4_1]).half()
+        model.cascade_matching_4c.forward(t4_0, t4_1, i01, i10, data, mask_c0=None, mask_c1=None, heatmap_c0=None, level="4c", pre_level="8c")
+        s4 = data["stage_4c"]
+        out.update(m4_b_ids=s4["b_ids"].to(torch.int16), m4_i_ids=s4["i_ids"].to(torch.int16), m4_j_ids=s4["j_ids"].to(torch.int16),
+                   m4_mconf=s4["mconf"], m4_mkpts0_c=s4["mkpts0_c"], m4_mkpts1_c=s4["mkpts1_c"])
+        w0, w1 = model.cas_fine_preprocess.forward(lf[:1], lf[1:], t4_0, t4_1, data=data)
+        if w0.size(0):
+            w0, w1 = model.cas_loftr_fine(w0, w1)
+        model.cas_fine_matching.forward(w0.float(), w1.float(), data)
+        out.update(mkpts0_f=data["mkpts0_f"], mkpts1_f=data["mkpts1_f"], expec_f=data["expec_f"])
+    out["thresholds"] = np.array([THRESHOLDS["coarse_thr"], THRESHOLDS["cascade_thr"], THRESHOLDS["pre_thr"], float(THRESHOLDS["double_check"])],
+                                 dtype=np.float32)
+    arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
+    path = os.path.join(HERE, "model_indoor_london_bridge.npz")
+    np.savez_compressed(path, **arrs)
+    print(f"model_indoor_london_bridge: {os.path.getsize(path) / 1e6:.2f} MB; coarse matches {len(s8['i_ids'])}, 1/4 matches {len(arrs['m4_i_ids'])}; "
+          f"|t8| {float(t8_0.abs().mean()):.3f} |t4| {float(t4_0.abs().mean()):.3f}; expec std {float(data['expec_f'][:, :2].std()) if len(data['expec_f']) else -1:.3f}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "2c":
+    if len(sys.argv) > 1 and sys.argv[1] == "indoor":
+        main_indoor()
+    elif len(sys.argv) > 1 and sys.argv[1] == "2c":
         main_2c()
     else:
         main()

@@ -31,14 +31,18 @@ def _config(fx):
     return c
 
 
-def _model(fx, device):
-    from casmtr_amd.model import CasMTR4c
-    m = CasMTR4c(_config(fx)).eval()
+def _load_deterministic(m):
     sd = m.state_dict()
     for k, v in model_state({k: tuple(v.shape) for k, v in sd.items()}).items():
-        sd[k] = torch.from_numpy(v)
+        if sd[k].dtype == torch.float32:   # integer buffers (window offsets, relative_position_index) keep their constructor values
+            sd[k] = torch.from_numpy(v)
     m.load_state_dict(sd)
-    return m.to(device)
+    return m
+
+
+def _model(fx, device):
+    from casmtr_amd.model import CasMTR4c
+    return _load_deterministic(CasMTR4c(_config(fx)).eval()).to(device)
 
 
 def _images(fx, device):
@@ -213,12 +217,7 @@ def _model2c(fx2, device):
     c["match_coarse"]["thr"] = float(thr[0])
     c["match_cascade"].update(test_thr=float(thr[1]), pre_thr=[float(thr[2])], double_check=bool(thr[3]))
     c["match_cascade_2c"].update(test_thr=float(thr[1]), pre_thr=[float(thr[2])] * 2, double_check=bool(thr[3]))
-    m = CasMTR2c(c).eval()
-    sd = m.state_dict()
-    for k, v in model_state({k: tuple(v.shape) for k, v in sd.items()}).items():
-        sd[k] = torch.from_numpy(v)
-    m.load_state_dict(sd)
-    return m.to(device)
+    return _load_deterministic(CasMTR2c(c).eval()).to(device)
 
 
 def test_state_dict_layout_2c_matches_reference():
@@ -334,3 +333,108 @@ def test_reduced_precision_convolutions(fx):
     assert mod._CONV_DTYPE[0] is None
     with pytest.raises(ValueError):
         m({"image0": im0[..., :100], "image1": im1[..., :100]})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the indoor model (cascade_quadtree_stage3.py): ResNet-FPN + ladder, 8 QuadTree layers, POLA, relative position bias, no NMS
+FIXI = os.path.join(HERE, "golden", "model_indoor_london_bridge.npz")
+
+
+@pytest.fixture(scope="module")
+def fxi():
+    z = np.load(FIXI)
+    return {k: z[k] for k in z.files}
+
+
+def _model_indoor(fxi, device):
+    from casmtr_amd.model import CasMTRIndoor4c, indoor_4c_config
+    c = indoor_4c_config()
+    thr = fxi["thresholds"]
+    c["match_coarse"]["thr"] = float(thr[0])
+    c["match_cascade"].update(test_thr=float(thr[1]), pre_thr=[float(thr[2])] * 2, double_check=bool(thr[3]))
+    return _load_deterministic(CasMTRIndoor4c(c).eval()).to(device)
+
+
+def test_state_dict_layout_indoor_matches_reference():
+    from casmtr_amd.model import CasMTRIndoor4c
+    with open(os.path.join(HERE, "golden", "model_indoor_state_keys.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v.shape) for k, v in CasMTRIndoor4c().state_dict().items()}
+    assert sorted(mine) == sorted(ref)
+    assert all(mine[k] == ref[k] for k in ref)
+
+
+def _indoor_torch_parts(fxi, device, tol):
+    """backbone, ladder and fine stage are torch ops only: they run on the CPU as well"""
+    m = _model_indoor(fxi, device)
+    im = [torch.from_numpy(fxi[k]).to(device).float() / 255.0 for k in ("image0", "image1")]
+    data = {"image0": im[0], "image1": im[1]}
+    with torch.no_grad():
+        x, f8, f4, ff = m.features(data)
+        _close(f8[:, ::4, ::2, ::2], fxi["bb_f8_sub"], tol, "1/8 features")
+        _close(f4[:, ::4, ::2, ::2], fxi["bb_f4_sub"], tol, "1/4 features")
+        _close(ff[:, ::4, ::4, ::4], fxi["bb_ff_sub"], tol, "1/2 features")
+        l4, lf = m.ladder(x, f4, ff)
+        _close(l4[:, ::4, ::2, ::2], fxi["lad_4_sub"], tol, "ladder 1/4")
+        _close(lf[:, ::4, ::4, ::4], fxi["lad_f_sub"], tol, "ladder 1/2")
+        t4 = torch.from_numpy(fxi["t4"]).to(device).float()
+        t = lambda k, dt=torch.int64: torch.from_numpy(fxi[k].astype(np.int64) if dt == torch.int64 else fxi[k]).to(device).to(dt)
+        data["stage_4c"] = {"b_ids": t("m4_b_ids"), "i_ids": t("m4_i_ids"), "j_ids": t("m4_j_ids"), "m_bids": t("m4_b_ids"),
+                            "mconf": t("m4_mconf", torch.float32), "mkpts0_c": t("m4_mkpts0_c", torch.float32),
+                            "mkpts1_c": t("m4_mkpts1_c", torch.float32)}
+        m.fine_stage(lf[:1], lf[1:], t4[:1], t4[1:], data)
+    assert len(fxi["mkpts1_f"]) >= 50
+    _close(data["mkpts0_f"], fxi["mkpts0_f"], 0, "mkpts0_f")
+    assert float((data["mkpts1_f"].cpu() - torch.from_numpy(fxi["mkpts1_f"])).abs().max()) < 1e-2   # pixels
+
+
+def test_indoor_backbone_ladder_fine_cpu(fxi):
+    _indoor_torch_parts(fxi, "cpu", 2e-4)
+
+
+@pytest.mark.gpu
+def test_indoor_backbone_ladder_fine_gpu(fxi):
+    _indoor_torch_parts(fxi, "cuda", 1e-3)
+
+
+@pytest.mark.gpu
+def test_indoor_stages_on_reference_tensors(fxi):
+    """8 QuadTree layers with top-k [32,16,16] on the fixture's fp16-exact 1/8 features; then ladder + UpBlock + POLA + cascade
+    cross-attention WITH the learned relative position bias on the reference's 1/8 tokens and argmax; then the matcher (no NMS)
+    on the reference's 1/4 tokens"""
+    m = _model_indoor(fxi, "cuda")
+    im = [torch.from_numpy(fxi[k]).cuda().float() / 255.0 for k in ("image0", "image1")]
+    data = {"image0": im[0], "image1": im[1]}
+    idx = lambda k: torch.from_numpy(fxi[k].astype(np.int64)).cuda()
+    with torch.no_grad():
+        x, f8, f4, ff = m.features(data)
+        t0, t1 = m.coarse_stage(torch.from_numpy(fxi["f8"]).cuda().float(), data)
+        _close(torch.cat([t0, t1]), fxi["t8"].astype(np.float32), 3e-3, "1/8 tokens", frac=0.99)
+        t8 = torch.from_numpy(fxi["t8"]).cuda().float()
+        data["stage_8c"] = {"next_idx_c01": idx("m8_next_idx_c01"), "next_idx_c10": idx("m8_next_idx_c10"),
+                            "next_conf_c01": torch.from_numpy(fxi["m8_next_conf_c01"]).cuda(), "next_conf_c01_s": None}
+        t4_0, t4_1, _, _ = m.cascade_stage(x, f4, ff, t8[:1], t8[1:], data)
+    _close(torch.cat([t4_0, t4_1]), fxi["t4"].astype(np.float32), 3e-3, "1/4 tokens")
+    from casmtr_amd import ops
+    t4 = torch.from_numpy(fxi["t4"]).cuda().float()
+    H4, W4 = data["hw0_4c"]
+    wi = [ops.WindowIndex(ops.window_warp_idx(data["stage_8c"][k], H4 // 2, W4 // 2, 5), (H4, W4), (H4, W4), 1)
+          for k in ("next_idx_c01", "next_idx_c10")]
+    m.cascade_matching_4c(t4[:1].contiguous(), t4[1:].contiguous(), wi[0], wi[1], data, level="4c", pre_level="8c")
+    s4 = data["stage_4c"]
+    assert len(fxi["m4_i_ids"]) >= 50
+    assert s4["i_ids"].cpu().tolist() == fxi["m4_i_ids"].astype(np.int64).tolist()
+    assert s4["j_ids"].cpu().tolist() == fxi["m4_j_ids"].astype(np.int64).tolist()
+    _close(s4["mconf"], fxi["m4_mconf"], 1e-4, "mconf")
+
+
+@pytest.mark.gpu
+def test_whole_forward_indoor(fxi):
+    m = _model_indoor(fxi, "cuda")
+    im = [torch.from_numpy(fxi[k]).cuda().float() / 255.0 for k in ("image0", "image1")]
+    data = m({"image0": im[0], "image1": im[1]})
+    mine = {(int(a[0]), int(a[1])): b for a, b in zip(data["mkpts0_f"].cpu().tolist(), data["mkpts1_f"].cpu())}
+    ref0, ref1 = fxi["mkpts0_f"], torch.from_numpy(fxi["mkpts1_f"])
+    hit = sum(1 for a, b in zip(ref0.tolist(), ref1) if (int(a[0]), int(a[1])) in mine
+              and float((mine[(int(a[0]), int(a[1]))] - b).abs().max()) < 0.25)
+    assert hit >= 0.85 * len(ref0), f"{hit} of {len(ref0)} reference matches reproduced ({len(mine)} found)"

@@ -21,7 +21,7 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--coarse-thr", type=float, default=None)
     ap.add_argument("--cascade-thr", type=float, default=None)
-    ap.add_argument("--model", choices=["4c", "2c"], default="4c")
+    ap.add_argument("--model", choices=["4c", "2c", "indoor"], default="4c")
     ap.add_argument("--conv-dtype", choices=["fp32", "fp16", "bf16"], default="fp32")
     a = ap.parse_args()
     print(json.dumps(time_whole_model(a.batch, a.size, a.steps, a.warmup, a.coarse_thr, a.cascade_thr, model=a.model,
