@@ -45,6 +45,7 @@ SIGNATURES = {
     "casmtr_dwconv3x3_tokens_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_layer_norm_fwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _F, _P]),
     "casmtr_window_attn_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "casmtr_pola_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "casmtr_prof_enable": (None, [_I]),
     "casmtr_debug_set": (None, [_I]),
     "casmtr_prof_enable_only": (_I, [_I]),

@@ -282,3 +282,124 @@ extern "C" int casmtr_window_attn_fwd(const float* qkv, float* out, int B, int H
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// POLA: patch-based overlapping self-attention of the indoor model's local blocks (NeighborWindowAttention + the window /
+// neighbourhood plumbing of POLATransBlock, src/model/modules/POLAttention.py:70-172, 280-320).  Queries of a ws x ws window attend
+// to the 3 x 3 windows around it (441 keys for ws = 7), with a learned bias indexed by the relative offset.
+// The reference pads the normalised map with zeros (to a multiple of ws, plus one window on every side), unfolds the 9x larger
+// neighbourhoods, projects them, and materialises [windows, heads, 49, 441] logits.  Here q, k0, v0 are the projections of the
+// UN-padded tokens (k0, v0 without bias: the key bias shifts all logits of a row by the same amount and the value bias is added by
+// the caller after the attention); a key position outside the map is the reference's zero padding: logit = bias only, value 0.
+//   s_j = (chain_d fmaf(q[d], k0_j[d])) * scale + bias[rel(q, j)];  o = (sum_j exp(s_j - max) v0_j) / (sum_j exp(s_j - max)),
+// running (max, sum) over the 9 neighbour windows, one 49-key window in LDS at a time.  One wave per (window, head).
+template <int WS>
+__global__ __launch_bounds__(256) void pola_attn_kernel(const float* __restrict__ q, const float* __restrict__ k0,
+                                                        const float* __restrict__ v0, const float* __restrict__ table,
+                                                        float* __restrict__ out, int H, int W, int NH, int GW, int GH, float scale) {
+    constexpr int T = WS * WS, SPAN = 4 * WS - 1;   // (n_win + 1) * ws - 1 with n_win = 3
+    __shared__ float kv[4][2][T][32];
+    __shared__ float tab[4][SPAN * SPAN];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int win = blockIdx.x;
+    const int wx = win % GW, wy = (win / GW) % GH, b = win / (GW * GH);
+    const int C = NH * 32;
+    const float* qb = q + (size_t)b * H * W * C;
+    const float* kb = k0 + (size_t)b * H * W * C;
+    const float* vb = v0 + (size_t)b * H * W * C;
+    float* ob = out + (size_t)b * H * W * C;
+    const int qy = lane / WS, qx = lane % WS;                      // lanes >= T idle along
+    const int ty = wy * WS + qy, tx = wx * WS + qx;
+    const bool act = lane < T && ty < H && tx < W;
+    const size_t tok = act ? (size_t)ty * W + tx : 0;
+    for (int h = wave; h < NH; h += 4) {
+        for (int i = lane; i < SPAN * SPAN; i += 64) tab[wave][i] = table[(size_t)i * NH + h];
+        float qr[32];
+        {
+            const f32x4* qp = reinterpret_cast<const f32x4*>(qb + tok * C + h * 32);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const f32x4 t = qp[p];
+                qr[4 * p] = t[0]; qr[4 * p + 1] = t[1]; qr[4 * p + 2] = t[2]; qr[4 * p + 3] = t[3];
+            }
+        }
+        float o[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        float m = -3.0e38f, sum = 0.f;
+        for (int nb = 0; nb < 9; ++nb) {
+            const int ny = nb / 3, nx = nb % 3;                    // neighbour window (ny - 1, nx - 1)
+            const int by = (wy + ny - 1) * WS, bx = (wx + nx - 1) * WS;
+            __builtin_amdgcn_wave_barrier();                       // previous chunk fully consumed
+            for (int j0 = 0; j0 < T; j0 += 8) {                    // stage the window's K and V rows (zeros outside the map)
+                const int j = j0 + (lane >> 3);
+                if (j < T) {
+                    const int yy = by + j / WS, xx = bx + j % WS;
+                    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        const size_t off = ((size_t)yy * W + xx) * C + h * 32 + (lane & 7) * 4;
+                        kk = *reinterpret_cast<const f32x4*>(kb + off);
+                        vv = *reinterpret_cast<const f32x4*>(vb + off);
+                    }
+                    *reinterpret_cast<f32x4*>(&kv[wave][0][j][(lane & 7) * 4]) = kk;
+                    *reinterpret_cast<f32x4*>(&kv[wave][1][j][(lane & 7) * 4]) = vv;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // relative index of key (ky, kx) of this neighbour for this lane's query: (qy - (ky + ny ws) + 3 ws - 1) * SPAN + (qx - (kx + nx ws) + 3 ws - 1)
+            const int ry0 = qy - ny * WS + 3 * WS - 1, rx0 = qx - nx * WS + 3 * WS - 1;
+            float s[T];
+            float cm = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const f32x4 kk = *reinterpret_cast<const f32x4*>(&kv[wave][0][j][4 * p]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fmaf(qr[4 * p + e], kk[e], a);
+                }
+                a = a * scale + tab[wave][(ry0 - j / WS) * SPAN + (rx0 - j % WS)];
+                cm = fmaxf(cm, a);
+                s[j] = a;
+            }
+            const float mn = fmaxf(m, cm);
+            const float corr = __expf(m - mn);
+            sum *= corr;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] *= corr;
+            m = mn;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const float p = __expf(s[j] - m);
+                sum += p;
+#pragma unroll
+                for (int pz = 0; pz < 8; ++pz) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(&kv[wave][1][j][4 * pz]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[4 * pz + e] = fmaf(p, vv[e], o[4 * pz + e]);
+                }
+            }
+        }
+        const float inv = 1.0f / sum;
+        if (act) {
+            f32x4* op = reinterpret_cast<f32x4*>(ob + tok * C + h * 32);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) op[p] = f32x4{o[4 * p] * inv, o[4 * p + 1] * inv, o[4 * p + 2] * inv, o[4 * p + 3] * inv};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int casmtr_pola_attn_fwd(const float* q, const float* k0, const float* v0, const float* bias_table, float* out, int B,
+                                    int H, int W, int nhead, int head_dim, int ws, float scale, casmtr_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (head_dim != 32 || ws != 7 || nhead <= 0) return CASMTR_ERR_UNSUPPORTED;
+    const int GW = (W + ws - 1) / ws, GH = (H + ws - 1) / ws;
+    ProfScope ps(CASMTR_PROF_GLUE, (hipStream_t)stream);
+    hipLaunchKernelGGL(pola_attn_kernel<7>, dim3((unsigned)(B * GW * GH)), dim3(256), 0, (hipStream_t)stream, q, k0, v0, bias_table,
+                       out, H, W, nhead, GW, GH, scale);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}

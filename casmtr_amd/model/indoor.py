@@ -19,7 +19,7 @@ from .. import ops
 from ..matching.cascade_matching import CascadeMatching
 from ..matching.coarse_matching import CoarseMatching
 from .casmtr4c import (CascadeQuadtreeBlock, CoarseTransformer, FinePreprocess, FineTransformer, SinePositionEncoding, UpBlock, _cv,
-                       _grid, _lin, _ln, _swap_halves, _tokens, fine_matching, _CONV_DTYPE)
+                       _fast, _grid, _lin, _ln, _swap_halves, _tokens, fine_matching, _CONV_DTYPE)
 
 
 def indoor_4c_config():
@@ -125,16 +125,20 @@ class _NeighbourWindowAttention(nn.Module):
         self.Wq, self.Wk, self.Wv = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
         self.proj = nn.Linear(dim, dim)
 
-    def forward(self, xq, xkv):
-        """xq [Bw, ws^2, C], xkv [Bw, (n ws)^2, C]"""
+    def forward(self, xq, k0, v0):
+        """xq [Bw, ws^2, C] window queries (un-projected); k0, v0 [Bw, (n ws)^2, C] neighbourhood keys / values already projected
+        WITHOUT their biases (zero at padded positions).  The reference projects the 9x larger unfolded neighbourhoods with bias;
+        the key bias adds q.b_k to every logit of a row (softmax-invariant) and the value bias adds b_v to every output (the
+        weights sum to 1), so projecting once per token before unfolding gives the same result."""
         Bw, Nq, C = xq.shape
         h, d = self.heads, C // self.heads
         q = _lin(self.Wq, xq).view(Bw, Nq, h, d).transpose(1, 2)
-        k = _lin(self.Wk, xkv).view(Bw, -1, h, d).transpose(1, 2)
-        v = _lin(self.Wv, xkv).view(Bw, -1, h, d).transpose(1, 2)
+        k = k0.view(Bw, -1, h, d).transpose(1, 2)
+        v = v0.view(Bw, -1, h, d).transpose(1, 2)
         bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(Nq, -1, h).permute(2, 0, 1)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias.unsqueeze(0).to(q.dtype), scale=self.scale)
-        return _lin(self.proj, o.transpose(1, 2).reshape(Bw, Nq, C))
+        o = o.transpose(1, 2).reshape(Bw, Nq, C) + self.Wv.bias
+        return _lin(self.proj, o)
 
 
 class _Mlp(nn.Module):
@@ -157,6 +161,21 @@ class POLABlock(nn.Module):   # POLATransBlock, POLAttention.py:244-332
     def forward(self, x, H, W):
         B, L, C = x.shape
         ws, n = self.ws, self.attn.n_win
+        at = self.attn
+        if _fast(x) and ws == 7 and C // at.heads == 32:
+            # three projections of the un-padded tokens in one launch, then one kernel for the neighbourhood attention: no padding,
+            # no 9x unfold, no [windows, heads, 49, 441] logits in HBM
+            xn = _ln(self.norm1, x)
+            dt = _CONV_DTYPE[0]
+            if dt is None:
+                q, k0, v0 = ops.linear_multi([xn, xn, xn], [at.Wq.weight, at.Wk.weight, at.Wv.weight], [at.Wq.bias, None, None])
+            else:   # reduced glue precision: the projections only; the attention itself stays fp32
+                xh = xn.to(dt)
+                q = F.linear(xh, at.Wq.weight.to(dt), at.Wq.bias.to(dt)).float()
+                k0, v0 = F.linear(xh, at.Wk.weight.to(dt)).float(), F.linear(xh, at.Wv.weight.to(dt)).float()
+            a = ops.pola_attn(q, k0, v0, at.relative_position_bias_table.contiguous(), H, W, at.heads, ws, at.scale) + at.Wv.bias
+            x = x + _lin(at.proj, a)
+            return x + self.mlp(_ln(self.norm2, x))
         xn = _ln(self.norm1, x).view(B, H, W, C)
         pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
         xn = F.pad(xn, (0, 0, 0, pr, 0, pb))                                           # zero padding takes part as keys, as in the reference
@@ -164,10 +183,13 @@ class POLABlock(nn.Module):   # POLATransBlock, POLAttention.py:244-332
         gh, gw = Hp // ws, Wp // ws
         xq = xn.view(B, gh, ws, gw, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B * gh * gw, ws * ws, C)
         m = (n // 2) * ws
-        kv = F.pad(xn, (0, 0, m, m, m, m)).permute(0, 3, 1, 2)                           # [B, C, Hp + 2m, Wp + 2m]
-        kv = F.unfold(kv, n * ws, stride=ws)                                             # [B, C (n ws)^2, gh gw]
-        kv = kv.permute(0, 2, 1).reshape(B * gh * gw, C, (n * ws) ** 2).permute(0, 2, 1)
-        a = self.attn(xq, kv).view(B, gh, gw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+
+        def neighbourhoods(t):   # [B, Hp, Wp, C] -> [B gh gw, (n ws)^2, C]: the n x n windows around every window, zero outside
+            u = F.unfold(F.pad(t, (0, 0, m, m, m, m)).permute(0, 3, 1, 2), n * ws, stride=ws)      # [B, C (n ws)^2, gh gw]
+            return u.permute(0, 2, 1).reshape(B * gh * gw, C, (n * ws) ** 2).permute(0, 2, 1)
+        k0 = F.linear(xn, self.attn.Wk.weight)       # bias-free projections of the (padded) map, once per token
+        v0 = F.linear(xn, self.attn.Wv.weight)
+        a = self.attn(xq, neighbourhoods(k0), neighbourhoods(v0)).view(B, gh, gw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
         x = x + a[:, :H, :W, :].reshape(B, L, C)
         return x + self.mlp(_ln(self.norm2, x))
 

@@ -241,6 +241,20 @@ def window_attn(qkv, H, W, nhead, ws, scale):
     return y
 
 
+def pola_attn(q, k0, v0, bias_table, H, W, nhead, ws, scale):
+    """POLA neighbourhood attention (3 x 3 windows of ws x ws around each query window, relative position bias) on un-padded
+    projected tokens q, k0, v0 [B,H*W,C] (k0, v0 bias-free) -> [B,H*W,C]; head_dim 32, ws 7."""
+    _chk(q, "q"), _chk(k0, "k0"), _chk(v0, "v0"), _chk(bias_table, "bias_table")
+    B, HW, Cc = q.shape
+    if HW != H * W or k0.shape != q.shape or v0.shape != q.shape or tuple(bias_table.shape) != ((4 * ws - 1) ** 2, nhead):
+        raise RuntimeError("pola_attn: q, k0, v0 must be [B, H*W, C] and bias_table [(4 ws - 1)^2, nhead]")
+    y = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().casmtr_pola_attn_fwd(_ptr(q), _ptr(k0), _ptr(v0), _ptr(bias_table), _ptr(y), B, H, W, nhead, Cc // nhead, ws,
+                                                   float(scale), _stream()), "pola_attn_fwd")
+    return y
+
+
 def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
     """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")

@@ -199,6 +199,17 @@ int casmtr_layer_norm_fwd(const float* x, const float* gamma, const float* beta,
 int casmtr_window_attn_fwd(const float* qkv, float* out, int B, int H, int W, int nhead, int head_dim, int ws, float scale,
                            casmtr_stream_t stream);
 
+/* POLA neighbourhood self-attention of the indoor model's local blocks (NeighborWindowAttention + the unfold plumbing of
+ * POLATransBlock, src/model/modules/POLAttention.py:70-172, 280-320): the queries of a ws x ws window attend to the 3 x 3 windows
+ * around it; bias_table [(4 ws - 1)^2, nhead] is relative_position_bias_table, indexed by (qy - ky + 3 ws - 1) * (4 ws - 1) +
+ * (qx - kx + 3 ws - 1) with key coordinates inside the 3 ws x 3 ws neighbourhood.  q, k0, v0, out [B,H*W,nhead*head_dim]: projections
+ * of the un-padded tokens, k0 / v0 WITHOUT bias (a key bias shifts every logit of a row equally; the caller adds the value bias to
+ * the output).  Key positions outside the map are the reference's zero padding: logit = bias, value 0.
+ *   s_j = (chain_d fmaf(q[d], k0_j[d])) * scale + bias[rel]; o = (sum_j exp(s_j - max) v0_j) / (sum_j exp(s_j - max)), running max / sum
+ * over the nine windows.  head_dim == 32 and ws == 7, otherwise CASMTR_ERR_UNSUPPORTED.                                        */
+int casmtr_pola_attn_fwd(const float* q, const float* k0, const float* v0, const float* bias_table, float* out, int B, int H, int W,
+                         int nhead, int head_dim, int ws, float scale, casmtr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart): per-kernel launch durations from HIP events recorded on the
  * launch stream.  Off by default.  casmtr_prof_enable(1) starts a fresh collection; casmtr_prof_read() waits for

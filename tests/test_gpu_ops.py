@@ -501,3 +501,38 @@ def test_window_attn_vs_oracle_and_torch(B, H, W, nh):
     assert float((got - ref).abs().max()) < 2e-5
     with pytest.raises(RuntimeError):
         ops.window_attn(qt, H, W, nh, 5, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,nh", [(2, 14, 21, 4), (1, 13, 9, 4), (1, 30, 40, 2), (1, 5, 3, 8)])
+def test_pola_attn_vs_reference_formulation(B, H, W, nh):
+    """casmtr_pola_attn_fwd against the reference's formulation restated on torch ops: pad to a multiple of 7, one more window of
+    zeros all round, unfold the 21 x 21 neighbourhoods, project them WITH bias, add the relative position bias, softmax"""
+    import torch.nn.functional as F
+    from casmtr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(H * 100 + W)
+    Cc, ws, n = nh * 32, 7, 3
+    x = torch.randn(B, H * W, Cc, device="cuda", generator=g)
+    Wq, Wk, Wv = (torch.randn(Cc, Cc, device="cuda", generator=g) / Cc ** 0.5 for _ in range(3))
+    bq, bk, bv = (0.3 * torch.randn(Cc, device="cuda", generator=g) for _ in range(3))
+    table = 0.5 * torch.randn((4 * ws - 1) ** 2, nh, device="cuda", generator=g)
+    scale = 32 ** -0.5
+    got = ops.pola_attn(F.linear(x, Wq, bq).contiguous(), F.linear(x, Wk).contiguous(), F.linear(x, Wv).contiguous(), table, H, W, nh, ws,
+                        scale) + bv
+    # ---- reference formulation
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    xp = F.pad(x.view(B, H, W, Cc), (0, 0, 0, pr, 0, pb))
+    Hp, Wp = H + pb, W + pr
+    gh, gw = Hp // ws, Wp // ws
+    xq = xp.view(B, gh, ws, gw, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B * gh * gw, ws * ws, Cc)
+    kv = F.unfold(F.pad(xp, (0, 0, ws, ws, ws, ws)).permute(0, 3, 1, 2), n * ws, stride=ws)
+    kv = kv.permute(0, 2, 1).reshape(B * gh * gw, Cc, (n * ws) ** 2).permute(0, 2, 1)
+    hd = lambda t: t.view(t.shape[0], t.shape[1], nh, 32).transpose(1, 2)
+    q, k, v = hd(F.linear(xq, Wq, bq)) * scale, hd(F.linear(kv, Wk, bk)), hd(F.linear(kv, Wv, bv))
+    qq = torch.arange(ws, device="cuda"); kk = torch.arange(n * ws, device="cuda")
+    qy, qx = torch.meshgrid(qq, qq, indexing="ij"); ky, kx = torch.meshgrid(kk, kk, indexing="ij")
+    idx = (qy.reshape(-1, 1) - ky.reshape(1, -1) + n * ws - 1) * (4 * ws - 1) + (qx.reshape(-1, 1) - kx.reshape(1, -1) + n * ws - 1)
+    bias = table[idx.view(-1)].view(ws * ws, -1, nh).permute(2, 0, 1)
+    att = (q @ k.transpose(-2, -1) + bias.unsqueeze(0)).softmax(-1)
+    ref = (att @ v).transpose(1, 2).reshape(B, gh, gw, ws, ws, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, Cc)[:, :H, :W].reshape(B, H * W, Cc)
+    assert float((got - ref).abs().max()) < 5e-5
