@@ -438,3 +438,34 @@ def test_whole_forward_indoor(fxi):
     hit = sum(1 for a, b in zip(ref0.tolist(), ref1) if (int(a[0]), int(a[1])) in mine
               and float((mine[(int(a[0]), int(a[1]))] - b).abs().max()) < 0.25)
     assert hit >= 0.85 * len(ref0), f"{hit} of {len(ref0)} reference matches reproduced ({len(mine)} found)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,size,B", [("CasMTR4c", (480, 640), 3), ("CasMTR4c", (256, 256), 1), ("CasMTR2c", (320, 256), 2),
+                                        ("CasMTRIndoor4c", (480, 640), 2), ("CasMTRIndoor4c", (256, 384), 1)])
+def test_models_run_at_other_sizes(cls, size, B):
+    """grids that are not multiples of the 7 x 7 attention windows, odd coarsest levels, several batch sizes: the forward pass runs,
+    is finite and puts every match inside the images; two runs agree up to the run-to-run round-off of the library GEMMs /
+    convolutions in the glue (the hot path itself is bit-reproducible: test_full_size_run_to_run_determinism)"""
+    import casmtr_amd.model as M
+    torch.manual_seed(0)
+    m = getattr(M, cls)()
+    for k, c in (("match_coarse", m.config["match_coarse"]), ("match_cascade", m.config["match_cascade"])):
+        c.update(thr=0.0) if k == "match_coarse" else c.update(test_thr=0.0, pre_thr=[0.0, 0.0], double_check=False)
+    if "match_cascade_2c" in m.config:
+        m.config["match_cascade_2c"].update(test_thr=0.0, pre_thr=[0.0, 0.0], double_check=False)
+    m = getattr(M, cls)(m.config).eval().cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    im0, im1 = (torch.rand((B, 3, *size), device="cuda", generator=g) for _ in range(2))
+    a = m({"image0": im0, "image1": im1})
+    b = m({"image0": im0, "image1": im1})
+    assert a["mkpts0_f"].shape[0] > 0
+    for k in ("mkpts0_f", "mkpts1_f", "expec_f"):
+        assert torch.isfinite(a[k]).all()
+    assert abs(a["mkpts0_f"].shape[0] - b["mkpts0_f"].shape[0]) <= 0.01 * a["mkpts0_f"].shape[0] + 2
+    if a["mkpts0_f"].shape == b["mkpts0_f"].shape and torch.equal(a["mkpts0_f"], b["mkpts0_f"]):
+        assert float((a["mkpts1_f"] - b["mkpts1_f"]).abs().max()) < 0.05   # pixels
+    assert int(a["m_bids"].max()) < B
+    H, W = size
+    assert (a["mkpts0_f"][:, 0] >= 0).all() and (a["mkpts0_f"][:, 0] < W).all() and (a["mkpts0_f"][:, 1] < H).all()
+    assert (a["mkpts1_f"] > -8).all() and (a["mkpts1_f"][:, 0] < W + 8).all() and (a["mkpts1_f"][:, 1] < H + 8).all()
