@@ -218,7 +218,9 @@ class HotPath(torch.nn.Module):
         self.eval()
 
     @torch.no_grad()
-    def forward(self, inp) -> Dict[str, object]:
+    def forward(self, inp, finalize: bool = True) -> Dict[str, object]:
+        """finalize=False: everything is enqueued, nothing is read back (no host sync); call finalize(out) later -- lets a driver
+        keep a second batch in flight on another stream while this one's match counts travel to the host"""
         cfg = self.cfg
         h8, w8 = cfg.hw8
         data = {"hw0_i": cfg.image_hw, "hw1_i": cfg.image_hw, "hw0_8c": (h8, w8), "hw1_8c": (h8, w8)}
@@ -274,13 +276,19 @@ class HotPath(torch.nn.Module):
             self.cascade_matching[si](inp[f"feat_{lvl}0"], inp[f"feat_{lvl}1"], idx01, idx10, data, mask_c0=mk[0], mask_c1=mk[1],
                                       level=lvl, pre_level=pre_levels[0] if len(pre_levels) == 1 else list(pre_levels))
             prev = lvl
-        # one host sync for the whole step: the match counts of every stage
-        for st in cfg.stages:
+        out = {"messages": msgs, "data": data}
+        return self.finalize(out) if finalize else out
+
+    def finalize(self, out) -> Dict[str, object]:
+        """one host sync for the whole step: the match counts of every stage"""
+        data = out["data"]
+        for st in self.cfg.stages:
             CascadeMatching.finalize(data, st.level)
         CoarseMatching.finalize(data, "8c")
-        last = data[f"stage_{cfg.stages[-1].level}"]
-        return {"messages": msgs, "data": data, "m_bids": last["m_bids"], "mkpts0": last["mkpts0_c"],
-                "mkpts1": last["mkpts1_c"], "mconf": last["mconf"], "n_coarse": data["stage_8c"]["b_ids"].numel()}
+        last = data[f"stage_{self.cfg.stages[-1].level}"]
+        out.update(m_bids=last["m_bids"], mkpts0=last["mkpts0_c"], mkpts1=last["mkpts1_c"], mconf=last["mconf"],
+                   n_coarse=data["stage_8c"]["b_ids"].numel())
+        return out
 
 
 # ----------------------------------------------------------------------------------------------- algorithmic work
