@@ -19,30 +19,29 @@ for i in range(N):
     model(inps[i % 2])
 torch.cuda.synchronize()
 one = (time.perf_counter() - t0) / N * 1e3
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-for s in streams:
-    s.wait_stream(torch.cuda.current_stream())
+res = {"config": cfg.name, "ms_per_step_1_in_flight": round(one, 3)}
+for NS in (2, 3, 4):
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
 
+    def enqueue(i):
+        with torch.cuda.stream(streams[i % NS]):
+            return model(inps[i % 2], finalize=False)
 
-def enqueue(i):
-    with torch.cuda.stream(streams[i % 2]):
-        return model(inps[i % 2], finalize=False)
+    def finish(i, out):
+        with torch.cuda.stream(streams[i % NS]):
+            return model.finalize(out)
 
-
-def finish(i, out):
-    with torch.cuda.stream(streams[i % 2]):
-        return model.finalize(out)
-
-
-for rep in range(2):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pend = enqueue(0)
-    for i in range(N):
-        nxt = enqueue(i + 1) if i + 1 < N else None
-        finish(i, pend)
-        pend = nxt
-    torch.cuda.synchronize()
-    two = (time.perf_counter() - t0) / N * 1e3
-print(json.dumps({"config": cfg.name, "ms_per_step_one_in_flight": round(one, 3), "ms_per_step_two_in_flight": round(two, 3),
-                  "pairs_per_s": [round(8e3 / one, 1), round(8e3 / two, 1)]}))
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pend = [enqueue(i) for i in range(NS - 1)]
+        for i in range(N):
+            if i + NS - 1 < N:
+                pend.append(enqueue(i + NS - 1))
+            finish(i, pend.pop(0))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / N * 1e3
+    res[f"ms_per_step_{NS}_in_flight"] = round(ms, 3)
+print(json.dumps(res))
