@@ -29,6 +29,11 @@ SIGNATURES = {
     "casmtr_qta_coarse_level_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_qta_coarse_level_ws_floats": (_SZ, [_I] * 4),
     "casmtr_qta_fine_level_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "casmtr_nchw_to_quads_multi": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "casmtr_tokens_to_quads": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "casmtr_topk_idx_to_tab": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "casmtr_qta_fine_level_quad_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
+    "casmtr_qta_coarse_level_tab_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_cascade_attn_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P] + [_I] * 8 + [_P]),
     "casmtr_window_warp_idx": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_dual_softmax_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _I, _P, _I, _I, _I, _I, _I, _P, _P,
@@ -52,7 +57,7 @@ SIGNATURES = {
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
 }
-PROF_COUNT = 17
+PROF_COUNT = 18
 
 
 def prof_enable(on: bool):
@@ -102,7 +107,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if l.casmtr_abi_version() != 2:
+        if l.casmtr_abi_version() != 3:
             raise RuntimeError("libcasmtr_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -253,19 +253,13 @@ static int launch_cas(const float* q, const float* key, const float* value, cons
     const size_t lds = sizeof(float) * 2 * (128 * 4 + 4 * H * 32 + 2 * 2048);   // 40 KB at H = 4: 4 workgroups (8 waves) per CU
     // persistent grid: exactly the workgroups that are resident at once (a workgroup that had to wait for a slot would start
     // its statically assigned share of the quads late)
-    static int resident[2] = {0, 0};
-    if (!resident[rel != nullptr]) {
-        int dev = 0, ncu = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess)
-            e = rel ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cascade_attn_dma_kernel<H, NP1, true>, 128, lds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cascade_attn_dma_kernel<H, NP1, false>, 128, lds);
-        if (e != hipSuccess || ncu <= 0 || per_cu <= 0) return e != hipSuccess ? (int)e : CASMTR_ERR_UNSUPPORTED;
-        resident[rel != nullptr] = ncu * per_cu / 8 * 8;
-    }
+    static int resident_tab[2][CASMTR_MAX_DEVICES] = {{0}, {0}};
+    int resident = 0;
+    if (const int r = rel ? resident_workgroups(resident_tab[1], cascade_attn_dma_kernel<H, NP1, true>, 128, lds, &resident)
+                          : resident_workgroups(resident_tab[0], cascade_attn_dma_kernel<H, NP1, false>, 128, lds, &resident))
+        return r;
     const long long work = (long long)B * nquads;
-    long long blocks = resident[rel != nullptr];
+    long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
     ProfScope ps(CASMTR_PROF_CASCADE_ATTN, s);
     if (rel)

@@ -208,3 +208,29 @@ struct ProfScope {
     } while (0)
 
 #define CASMTR_ERR_UNSUPPORTED 1001  // shape outside what the kernel was built for (caller must not fall back to CPU)
+
+// Size of a persistent grid: the workgroups of `kernel` that are resident at once on the CURRENT device (CU count x occupancy, a
+// multiple of 8 so that every XCD gets the same number).  Cached per device id -- a process may drive several parts, or partition
+// modes with different CU counts -- with relaxed atomics (concurrent first calls compute the same value).
+#define CASMTR_MAX_DEVICES 64
+template <typename KernelT>
+static inline int resident_workgroups(int* cache /* [CASMTR_MAX_DEVICES], zero-initialised */, KernelT kernel, int threads, size_t lds,
+                                      int* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= CASMTR_MAX_DEVICES) return CASMTR_ERR_UNSUPPORTED;
+    int r = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+    if (!r) {
+        int ncu = 0, per_cu = 0;
+        e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds);
+        if (e != hipSuccess) return (int)e;
+        if (ncu <= 0 || per_cu <= 0) return CASMTR_ERR_UNSUPPORTED;
+        r = ncu * per_cu / 8 * 8;
+        if (r <= 0) return CASMTR_ERR_UNSUPPORTED;
+        __atomic_store_n(&cache[dev], r, __ATOMIC_RELAXED);
+    }
+    *out = r;
+    return 0;
+}

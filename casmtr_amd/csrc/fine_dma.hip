@@ -328,19 +328,13 @@ template <int NPASS, bool EXACT>
 static int launch_fine(const FineArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * 2 * (64 * NPASS * 4 + 2 * 128 + 2 * 32 + 2 * 2048);
     // persistent grid: exactly the workgroups that are resident at once
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, ncu = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fine_level_dma_kernel<NPASS, EXACT>, 128, lds);
-        if (e != hipSuccess || ncu <= 0 || per_cu <= 0) return e != hipSuccess ? (int)e : CASMTR_ERR_UNSUPPORTED;
-        resident = ncu * per_cu / 8 * 8;
-    }
+    static int resident_tab[CASMTR_MAX_DEVICES] = {0};
+    int resident = 0;
+    if (const int r = resident_workgroups(resident_tab, fine_level_dma_kernel<NPASS, EXACT>, 128, lds, &resident)) return r;
     const long long work = (long long)a.B * a.nquads * a.H;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
-    ProfScope ps(CASMTR_PROF_QTA_FINE, s);
+    ProfScope ps(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, s);
     hipLaunchKernelGGL((fine_level_dma_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;

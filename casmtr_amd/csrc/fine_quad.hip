@@ -1,0 +1,513 @@
+// QTAttB.process_fine_level + its share of the message merge (cuda_imp/QuadTreeAttention/QuadtreeAttention/modules/
+// quadtree_attention.py:180-229,262-284) on QUAD-MAJOR operands: the round-3 fine-level kernel.
+//
+// Layout ("quad-major per head", produced by casmtr_nchw_to_quads_multi straight from the module's NCHW pyramids, at the cost the
+// token-major conversion had):  x_qm[b][h][Q][c][d], Q = (r/2)*(w/2) + (c/2) the quad of token (r, c), c = (r&1)*2 + (c&1) its child
+// slot, d < 32.  A parent selected at the previous level IS a quad index of this level's key grid, so
+//   * the 4 children of a parent (:193-199) are ONE contiguous 512-byte run -- no (row, col) decomposition, no integer division per
+//     candidate, 4 lines per address instead of 1 (token-major: 4 separate 128-byte rows in two image rows, 1 KB apart per token);
+//   * a (pair, head) slice of K or V is one contiguous 1.4 MB block (head <-> XCD affinity keeps it in that XCD's L2);
+//   * the 4 queries of an item are one contiguous 512-byte run.
+// The previous level's top-k arrives as a compact int32 table parents[b][h][quad][Kp] (written by the previous level's kernel next
+// to -- or instead of -- the reference's int64 [B,L,K,H] tensor, whose 8-byte entries at a 64-byte stride made every XCD fetch all
+// eight heads' lines: 8x over-fetch of the index stream).
+//
+// Structure: persistent single-wave workgroups, ~10 KB of LDS each (14-16 waves per CU; the round-2 kernel: 8), one (quad, head) item
+// per wave at a time.  K and V rows come in by LDS-DMA in 4 KB chunks (8 parents = 32 candidate rows = 4 wave-instructions behind ONE
+// M0 write: the instruction's immediate offset advances the LDS destination and the source together, tools/probes/glds_offset.hip)
+// through a two-slot ring:
+//   K pass (64 candidates = both slots): lane <-> candidate, 32 v_mfma_f32_4x4x1_16B_f32 = the exact d-ascending fmaf chain of the
+//     oracle (tools/probes/mfma4x4_layout.hip), so the logits and every index derived from them are bit-identical;
+//   softmax: one series (child) per 16-lane DPP row;
+//   top-k (levels that feed a finer one): each lane sorts its 8 packed keys (25 high bits of the ordered logit | 127 - position: ONE
+//     32-bit compare-exchange = v_max_u32 + v_min_u32), then a 4-round bitonic merge tree across the row keeps the 16 best: after it
+//     every lane pair holds the sorted top-16, lane j reads rank (j&1)*8 + j/2 out of its own registers and the row stores the list
+//     with ONE instruction per output tensor (round 2: 16 rounds of row-argmax with a divergent one-lane store each, ~50 VALU per
+//     extracted element).  The packed order equals the exact (logit desc, position asc) order unless two of the 17 best share their 25
+//     high bits; that is checked (adjacent ranks + a count of elements >= the last rank's bucket) and such waves -- exact ties, logits
+//     closer than 2^-16 relative -- redo the selection with the exact iterated argmax;
+//   V chunks (32 rows): 16 v_mfma_f32_4x4x1 each (two rows per instruction), probabilities as operand A from 4 ds_read_b128.
+// Results are in raster order of the h0 x w0 grid; final = final[parent] + message * weight (:277-281) fused into the store.
+#include "common.hpp"
+#include "../../include/casmtr_hip.h"
+
+using namespace casmtr;
+
+struct FineQArgs {
+    const float* q;          // [B,H,Lq0,4,32]
+    const float* key;        // [B,H,Lq1,4,32]
+    const float* value;      // [B,H,Lq1,4,32]
+    const int32_t* parents;  // [B,H,Lq0,Kp] quad index on the key grid (= the previous level's absolute top-k index)
+    const float* acc_in;     // nullable [B,Lq0,H*32]
+    float* message;          // nullable [B,L,H*32]
+    float* acc_out;          // nullable [B,L,H*32]
+    int32_t* topk_tab;       // nullable [B,H,L,topk]: this level's top-k as the next level's parents table
+    float* topk_score;       // nullable [B,L,topk,H]
+    int64_t* topk_idx;       // nullable [B,L,topk,H]
+    float temp, w_level;
+    int topk, B, h0, w0, h1, w1, H, Kp, nquads, lq1;
+    unsigned div_magic;      // ceil(2^32 / (w1/2)): p / (w1/2) == umulhi(p, div_magic) for p < 2^22 (0: w1/2 == 1)
+};
+
+// one 4 KB chunk: 4 LDS-DMA instructions, lane-linear 1 KB each.  The source offsets o1..o3 are pre-biased by -1024, -2048, -3072
+// (the immediate offset is added to BOTH addresses) and every offset by +3072 against a base pointer that is 3072 bytes low, so
+// that they stay non-negative.  M0 is neither saved nor restored: nothing else in these kernels uses it (tools/check_fine_quad_isa.py).
+__device__ __forceinline__ void glds_chunk(const float* base_m3072, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %4\n\t"
+                 "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %3, %4 offset:3072"
+                 :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base_m3072), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ unsigned row16_sum_u32(unsigned v) {
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    v += dpp_u32<0x141>(v);
+    v += dpp_u32<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ void ce_desc(unsigned& a, unsigned& b) {   // compare-exchange: a >= b afterwards
+    const unsigned hi = max(a, b), lo = min(a, b);
+    a = hi; b = lo;
+}
+// descending sort of 8 registers (optimal 19-comparator network) and of a bitonic 8-sequence (12 comparators)
+__device__ __forceinline__ void sort8_desc(unsigned (&s)[8]) {
+    ce_desc(s[0], s[1]); ce_desc(s[2], s[3]); ce_desc(s[4], s[5]); ce_desc(s[6], s[7]);
+    ce_desc(s[0], s[2]); ce_desc(s[1], s[3]); ce_desc(s[4], s[6]); ce_desc(s[5], s[7]);
+    ce_desc(s[1], s[2]); ce_desc(s[5], s[6]); ce_desc(s[0], s[4]); ce_desc(s[3], s[7]);
+    ce_desc(s[1], s[5]); ce_desc(s[2], s[6]);
+    ce_desc(s[1], s[4]); ce_desc(s[3], s[6]);
+    ce_desc(s[2], s[4]); ce_desc(s[3], s[5]);
+    ce_desc(s[3], s[4]);
+}
+__device__ __forceinline__ void bitonic8_desc(unsigned (&s)[8]) {
+    ce_desc(s[0], s[4]); ce_desc(s[1], s[5]); ce_desc(s[2], s[6]); ce_desc(s[3], s[7]);
+    ce_desc(s[0], s[2]); ce_desc(s[1], s[3]); ce_desc(s[4], s[6]); ce_desc(s[5], s[7]);
+    ce_desc(s[0], s[1]); ce_desc(s[2], s[3]); ce_desc(s[4], s[5]); ce_desc(s[6], s[7]);
+}
+// One round of the merge tree.  Before: every lane pair (even, odd) of a group of G lanes holds the sorted top-16 of the group's
+// elements (even lane: ranks 0-7 in s[0..7], odd lane: ranks 8-15); CTRL mirrors the 2G-lane group (lane k <- lane 2G-1-k), so an even
+// lane reads the OTHER group's ranks 15-i and an odd lane its ranks 7-i: max() of the two is the bitonic top-16 of both groups,
+// which one cross-lane step (distance 8: even keeps max, odd keeps min) and an in-lane bitonic sort put in order.  After: the same
+// invariant for groups of 2G lanes.
+template <int CTRL>
+__device__ __forceinline__ void merge_round(unsigned (&s)[8], bool odd) {
+    unsigned x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = max(s[i], dpp_u32<CTRL>(s[7 - i]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned t = dpp_u32<0xB1>(x[i]);
+        s[i] = odd ? min(x[i], t) : max(x[i], t);
+    }
+    bitonic8_desc(s);
+}
+
+template <int NPASS, bool EXACT>   // EXACT: the level feeds a finer one (top-k requested): bit-exact sequential d-chain
+__global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(const FineQArgs a) {
+    constexpr int KMAX = 64 * NPASS;
+    constexpr int E = KMAX / 16;          // elements per lane in the series-per-row phase
+    constexpr int KS = KMAX + 4;          // row stride of the logits transposition buffer
+    constexpr int PST = 32 * NPASS + 4;   // stride of one (child, parity) run of probabilities
+    constexpr int P_FLOATS = 8 * PST;
+    constexpr int NV = 2 * NPASS;         // V chunks per item
+    static_assert(P_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    float* ring = smem;                                     // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
+    float* Pld = ring + 2048;                               // P[child][parity][m] (candidate 2m + parity); first the [4][KS] logits
+    float* qs = Pld + P_FLOATS;                             // [4 children][32]
+    int* t2 = reinterpret_cast<int*>(qs + 128);             // t2[parity * 16 + j] = parent 2j + parity
+    const int H = a.H, HD = H * 32, Kp = a.Kp, K = 4 * Kp;
+    const int L = a.h0 * a.w0, wq = a.w0 >> 1, Lq = a.nquads, w1p = a.w1 >> 1;
+    // ---- work list: XCD x -> head x % H; the 8 / H XCDs sharing a head split every pair's quads into contiguous chunks
+    const int xcd = blockIdx.x & 7, h = xcd % H, G = 8 / H, g = xcd / H;
+    const int chunk = (Lq + G - 1) / G, cnt = min(chunk, Lq - g * chunk);
+    const int total = cnt > 0 ? a.B * cnt : 0, stride = gridDim.x >> 3;
+    const int t = blockIdx.x >> 3;
+    if (g >= G || t >= total) return;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
+    const int un = lane & 7;
+    // DMA source offset inside a parent's 512-byte run.  Row r = 8 j + lane / 8 of a pass (j = DMA instruction 0..7); physical unit
+    // `un` of row r receives logical unit un ^ ((r >> 1) & 7): lane <-> candidate ds_read_b128 of the K pass is then conflict-free.
+    unsigned cK[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        cK[j] = (unsigned)(((lane >> 3) & 3) * 128 + ((un ^ (((j & 1) * 4 + (lane >> 4)) & 7)) * 16) + 3072 - j * 1024);
+    unsigned rd[8];    // K pass: byte offset of logical unit u of this lane's row
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rd[u] = (unsigned)(lane * 128 + ((u ^ ((lane >> 1) & 7)) * 16));
+    unsigned va[8];    // V chunk: byte offset of V[row 2 mm + lane/32][d = lane%32] for mm % 8 == x, minus mm * 256
+#pragma unroll
+    for (int x = 0; x < 8; ++x) va[x] = (unsigned)((lane >> 5) * 128 + ((((lane & 31) >> 2) ^ x) * 16) + (lane & 3) * 4);
+    const float* pa = Pld + ((lane & 3) * 2 + (lane >> 5)) * PST;   // operand A of the V chunks: P[child lane%4][parity lane/32][.]
+
+    // ---- per-item front end, run one item ahead: global -> registers (prefetch), registers -> LDS + DMA offsets (stage_in)
+    int pf_p = 0;
+    f32x4 pf_q = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float pf_acc = 0.f, acc_cur = 0.f, acc_nx = 0.f;   // final[parent] of the item for d = lane % 32 (:277)
+    struct Item { int b, quad, l00; };                  // pair, quad, first child's token (child f -> l00 + (f>>1)*w0 + (f&1))
+    int cb = t / cnt, cq = t % cnt, cy = (g * chunk + cq) / wq, cx = (g * chunk + cq) % wq;
+    const int sy = stride / wq, sx = stride % wq;
+    auto take = [&](Item& it) {   // -> false when the wave's list is exhausted
+        if (cb >= a.B) return false;
+        it.b = cb; it.quad = g * chunk + cq; it.l00 = 2 * cy * a.w0 + 2 * cx;
+        cq += stride;
+        if (cq >= cnt) {
+            while (cq >= cnt) { cq -= cnt; ++cb; }
+            cy = (g * chunk + cq) / wq; cx = (g * chunk + cq) % wq;
+        } else {
+            cy += sy; cx += sx;
+            if (cx >= wq) { cx -= wq; ++cy; }
+        }
+        return true;
+    };
+    auto prefetch = [&](const Item& it) {
+        const size_t qd = ((size_t)it.b * H + h) * Lq + it.quad;
+        if (lane < 32) {
+            pf_p = a.parents[qd * Kp + min(lane, Kp - 1)];
+            pf_q = *reinterpret_cast<const f32x4*>(a.q + qd * 128 + lane * 4);
+        }
+        if (a.acc_in) pf_acc = a.acc_in[((size_t)it.b * Lq + it.quad) * HD + h * 32 + (lane & 31)];
+    };
+    unsigned voff[NPASS][8];   // DMA instruction j of pass p: source offset of this lane's 16 bytes (rows 64p + 8j + lane/8)
+    auto stage_in = [&]() {
+        if (lane < 32) {
+            t2[(lane & 1) * 16 + (lane >> 1)] = pf_p;
+            *reinterpret_cast<f32x4*>(qs + lane * 4) = pf_q;
+        }
+        acc_nx = pf_acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 2 * NPASS; ++i) {
+            const int4 p4 = *reinterpret_cast<const int4*>(t2 + (lane >> 5) * 16 + 4 * i);
+            voff[i >> 1][(i & 1) * 4 + 0] = ((unsigned)p4.x << 9) + cK[0];
+            voff[i >> 1][(i & 1) * 4 + 1] = ((unsigned)p4.y << 9) + cK[1];
+            voff[i >> 1][(i & 1) * 4 + 2] = ((unsigned)p4.z << 9) + cK[2];
+            voff[i >> 1][(i & 1) * 4 + 3] = ((unsigned)p4.w << 9) + cK[3];
+        }
+    };
+    // chunk c of pass p (rows 64p + 32c ..) of K (isv = 0) or V (isv = 1) of pair b -> ring slot c
+    auto issue = [&](int isv, auto pc, auto cc, int b) {
+        constexpr int p = decltype(pc)::value, c = decltype(cc)::value;
+        const float* base = (isv ? a.value : a.key) + ((size_t)b * H + h) * a.lq1 * 128 - 768;   // wave-uniform; 3072 bytes low
+        glds_chunk(base, voff[p][4 * c + 0], voff[p][4 * c + 1], voff[p][4 * c + 2], voff[p][4 * c + 3], ring_lds + (unsigned)(c * 4096));
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    Item it_cur{}, it_nx{}, it_pf{};
+    take(it_cur);
+    prefetch(it_cur);
+    stage_in();
+    acc_cur = acc_nx;
+    // results of the previous item: stored right behind the next item's first DMA wait (vmcnt counts stores too, in order: a store
+    // issued just in front of a wait stalls the wave for its whole round trip)
+    f32x4 pend = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float pend_acc = 0.f, pend_sc = 0.f;
+    int pend_b = 0, pend_l00 = 0, pend_idx = 0;
+    bool have_pend = false;
+    auto flush = [&]() {
+        if (have_pend) {
+            const int hi = lane >> 5;
+            const float vA = hi ? pend[2] : pend[0], vB = hi ? pend[3] : pend[1];
+            const size_t o = ((size_t)pend_b * L + pend_l00 + hi * a.w0) * HD + h * 32 + (lane & 31);
+            if (a.message) { a.message[o] = vA; a.message[o + HD] = vB; }
+            if (a.acc_out) {   // separate multiply and add (:277-281)
+                a.acc_out[o] = pend_acc + vA * a.w_level;
+                a.acc_out[o + HD] = pend_acc + vB * a.w_level;
+            }
+            if constexpr (EXACT) {
+                const int f = lane >> 4, j = lane & 15, rank = (j & 1) * 8 + (j >> 1);
+                if (rank < a.topk) {
+                    const size_t lf = (size_t)pend_b * L + pend_l00 + (f >> 1) * a.w0 + (f & 1);
+                    if (a.topk_tab) a.topk_tab[(((size_t)pend_b * H + h) * L + (lf - (size_t)pend_b * L)) * a.topk + rank] = pend_idx;
+                    if (a.topk_idx) a.topk_idx[(lf * a.topk + rank) * H + h] = pend_idx;
+                    if (a.topk_score) a.topk_score[(lf * a.topk + rank) * H + h] = pend_sc;
+                }
+            }
+        }
+        have_pend = false;
+    };
+    issue(0, I0{}, I0{}, it_cur.b);
+    issue(0, I0{}, I1{}, it_cur.b);
+    bool more = take(it_nx), has_pf = false;
+    if (more) prefetch(it_nx);
+    for (;;) {
+        const int b = it_cur.b, l00 = it_cur.l00, bn = it_nx.b;
+        // ================================================================== K passes: logits of candidates 64p .. 64p+63
+        f32x4 lg[NPASS];
+        static_for<0, NPASS>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            glds_wait<0>();
+            if constexpr (p == 0) flush();
+            f32x4 qa[8], kr[8];   // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * 32 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ring) + rd[u]);
+            lds_reads_done();
+            if constexpr (p + 1 < NPASS) {   // the ring is free again: next pass of K
+                issue(0, std::integral_constant<int, (p + 1 < NPASS ? p + 1 : 0)>{}, I0{}, b);
+                issue(0, std::integral_constant<int, (p + 1 < NPASS ? p + 1 : 0)>{}, I1{}, b);
+            } else {                         // ... or the first two chunks of V
+                issue(1, I0{}, I0{}, b);
+                issue(1, I0{}, I1{}, b);
+            }
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (EXACT) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, c, 0, 0, 0);
+                }
+            } else {
+                // no index depends on these logits (finest level): four interleaved partial d-chains instead of one sequential chain
+                f32x4 c4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    c4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, c4[0], 0, 0, 0);
+                    c4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, c4[1], 0, 0, 0);
+                    c4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, c4[2], 0, 0, 0);
+                    c4[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].w, kr[u].w, c4[3], 0, 0, 0);
+                }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) c[f] = (c4[0][f] + c4[1][f]) + (c4[2][f] + c4[3][f]);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) lg[p][f] = a.temp * c[f];
+            asm volatile("" : "+v"(lg[p]));   // keep the pass's arithmetic inside the pass
+        });
+        // ================================================================== softmax (+ top-k), one series (child) per 16-lane row
+        const int f = lane >> 4, j = lane & 15;
+        {
+            float* Sld = Pld;   // [4][KS]
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp)
+#pragma unroll
+                for (int ff = 0; ff < 4; ++ff) Sld[ff * KS + 64 * pp + lane] = lg[pp][ff];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float lv[E];
+            unsigned xk[E];
+            const f32x4* sp = reinterpret_cast<const f32x4*>(Sld + f * KS + j * E);
+#pragma unroll
+            for (int e4 = 0; e4 < E / 4; ++e4) {
+                const f32x4 v = sp[e4];
+                lv[4 * e4 + 0] = v.x; lv[4 * e4 + 1] = v.y; lv[4 * e4 + 2] = v.z; lv[4 * e4 + 3] = v.w;
+            }
+            unsigned lm = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                xk[e] = (j * E + e < K) ? f2ord(lv[e]) : 0u;
+                lm = max(lm, xk[e]);
+            }
+            const float m = ord2f(row16_max_u32(lm));
+            float ps[E];
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ps[e] = (j * E + e < K) ? __expf(lv[e] - m) : 0.f;
+                sum += ps[e];
+            }
+            sum = 1.0f / row16_sum_f32(sum);
+#pragma unroll
+            for (int e = 0; e < E; ++e) ps[e] = ps[e] * sum;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // every lane has its logits: the buffer becomes P
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // candidate j*E + e -> P[f][e & 1][(j*E + e) >> 1]
+            if constexpr (E == 4) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2*>(Pld + (f * 2 + 0) * PST + 2 * j) = (f32x2){ps[0], ps[2]};
+                *reinterpret_cast<f32x2*>(Pld + (f * 2 + 1) * PST + 2 * j) = (f32x2){ps[1], ps[3]};
+            } else {
+                *reinterpret_cast<f32x4*>(Pld + (f * 2 + 0) * PST + 4 * j) = (f32x4){ps[0], ps[2], ps[4], ps[6]};
+                *reinterpret_cast<f32x4*>(Pld + (f * 2 + 1) * PST + 4 * j) = (f32x4){ps[1], ps[3], ps[5], ps[7]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (EXACT) {
+                // ---- selection on the logits, (logit desc, position asc); lane j ends up with rank (j&1)*8 + j/2
+                const bool odd = j & 1;
+                const int rank = (j & 1) * 8 + (j >> 1), topm1 = a.topk - 1;
+                unsigned s[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    s[e] = (e < E && xk[e < E ? e : 0] != 0u) ? ((xk[e < E ? e : 0] & ~127u) | (unsigned)(127 - (j * E + e))) : 0u;
+                sort8_desc(s);
+                unsigned loc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) loc[e] = s[e];
+                {   // round 1: the pair's 16 elements, sorted across (even, odd)
+                    unsigned x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned tt = dpp_u32<0xB1>(s[7 - i]);
+                        x[i] = odd ? min(s[i], tt) : max(s[i], tt);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s[i] = x[i];
+                    bitonic8_desc(s);
+                }
+                merge_round<0x1B>(s, odd);    // quad_perm [3,2,1,0]
+                merge_round<0x141>(s, odd);   // row_half_mirror
+                merge_round<0x140>(s, odd);   // row_mirror
+                unsigned mine = s[0];
+                {
+                    const int sel = j >> 1;
+                    const unsigned m01 = (sel & 1) ? s[1] : s[0], m23 = (sel & 1) ? s[3] : s[2];
+                    const unsigned m45 = (sel & 1) ? s[5] : s[4], m67 = (sel & 1) ? s[7] : s[6];
+                    const unsigned m03 = (sel & 2) ? m23 : m01, m47 = (sel & 2) ? m67 : m45;
+                    mine = (sel & 4) ? m47 : m03;
+                }
+                // is the packed order the exact order for the first topk ranks?  (see the file header)
+                bool bad = false;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) bad |= ((s[i] ^ s[i + 1]) < 128u) && ((odd ? 8 : 0) + i < topm1);
+                {
+                    const unsigned tt = dpp_u32<0xB1>(s[0]);
+                    bad |= !odd && ((s[7] ^ tt) < 128u) && (7 < topm1);
+                }
+                const int jstar = (topm1 & 7) * 2 + (topm1 >> 3);
+                const unsigned thr = row16_max_u32(j == jstar ? mine : 0u) & ~127u;
+                unsigned cntge = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cntge += (loc[e] >= thr) ? 1u : 0u;
+                bad |= row16_sum_u32(cntge) != (unsigned)a.topk;
+                int my_pos = 127 - (int)(mine & 127u);
+                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+                    // exact path: iterated row argmax on the full 32-bit keys, first position by ballot / ffs
+                    unsigned key[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) key[e] = xk[e];
+                    for (int tk = 0; tk < a.topk; ++tk) {
+                        unsigned cur = 0;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) cur = max(cur, key[e]);
+                        const unsigned rm = row16_max_u32(cur);
+                        const unsigned long long bal = __ballot(cur == rm);
+                        const unsigned bits = (unsigned)(bal >> (f * 16)) & 0xFFFFu;
+                        const int wj = __ffs(bits) - 1;   // first lane of the row holding the maximum -> smallest position
+                        unsigned kp1 = 0;
+                        if (j == wj) {
+                            bool done = false;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const bool hit = !done && key[e] == rm;
+                                if (hit) { kp1 = (unsigned)(j * E + e + 1); key[e] = 0u; done = true; }
+                            }
+                        }
+                        const unsigned wp1 = row16_max_u32(kp1);
+                        if (rank == tk) my_pos = (int)wp1 - 1;
+                    }
+                }
+                if (rank >= a.topk) my_pos = 0;
+                const int c = my_pos;
+                pend_sc = Pld[(f * 2 + (c & 1)) * PST + (c >> 1)];
+                const int par = t2[((c >> 2) & 1) * 16 + (c >> 3)];
+                const int qy1 = a.div_magic ? (int)__umulhi((unsigned)par, a.div_magic) : par;
+                const int qx1 = par - qy1 * w1p;
+                pend_idx = (2 * qy1 + ((c >> 1) & 1)) * a.w1 + 2 * qx1 + (c & 1);   // absolute index on the h1 x w1 grid (:224)
+            }
+        }
+        // ================================================================== V chunks; then the next item's K pass 0
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        static_for<0, NV>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c == NV - 2) {
+                if (more) stage_in();   // every chunk of this item has been issued: the offsets become the next item's
+            }
+            // in flight behind chunk c: chunk c + 1 (or the next item's first K chunk) = 4 instructions
+            if (c + 1 < NV || more) glds_wait<4>(); else glds_wait<0>();
+            if constexpr (c == NV - 2) {
+                // the item after next: issued behind the wait, a whole chunk ahead of the next one
+                has_pf = more && take(it_pf);
+                if (has_pf) prefetch(it_pf);
+            }
+            f32x4 pv[4];   // operand A of MFMA mm: P[child lane%4][parity lane/32][16 c + mm]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pa + 16 * c + 4 * i);
+            float vb[16];
+            const char* sb = reinterpret_cast<const char*>(ring) + (c & 1) * 4096;
+#pragma unroll
+            for (int mm = 0; mm < 16; ++mm) vb[mm] = *reinterpret_cast<const float*>(sb + va[mm & 7] + mm * 256);
+            lds_reads_done();
+            // the slot is free: chunk c + 2 of V, or the next item's K pass 0
+            if constexpr (c + 2 < NV) {
+                issue(1, std::integral_constant<int, ((c + 2) >> 1)>{}, std::integral_constant<int, (c & 1)>{}, b);
+            } else {
+                if (more) issue(0, I0{}, std::integral_constant<int, (c & 1)>{}, bn);
+            }
+#pragma unroll
+            for (int mm = 0; mm < 16; ++mm)
+                acc[mm & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(pv[mm >> 2][mm & 3], vb[mm], acc[mm & 3], 0, 0, 0);
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        });
+        {
+            f32x4 tot;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float x = (acc[0][c] + acc[1][c]) + (acc[2][c] + acc[3][c]);
+                const unsigned xi = __float_as_uint(x);
+                const auto sw = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);   // lanes l and l ^ 32
+                tot[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            pend = tot; pend_acc = acc_cur; pend_b = b; pend_l00 = l00; have_pend = true;
+        }
+        if (!more) break;
+        acc_cur = acc_nx;
+        it_cur = it_nx; it_nx = it_pf; more = has_pf;
+    }
+    glds_wait<0>();
+    flush();
+}
+
+template <int NPASS, bool EXACT>
+static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 128 + 32);
+    // persistent grid: exactly the workgroups that are resident at once
+    static int resident[CASMTR_MAX_DEVICES] = {0};
+    int res = 0;
+    if (const int r = resident_workgroups(resident, fine_quad_kernel<NPASS, EXACT>, 64, lds, &res)) return r;
+    const long long work = (long long)a.B * a.nquads * a.H;
+    long long blocks = res;
+    if (blocks > work) blocks = (work + 7) / 8 * 8;
+    ProfScope ps(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, s);
+    hipLaunchKernelGGL((fine_quad_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(64), lds, s, a);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, const float* value, const int32_t* parents, float temp,
+                                              int topk, float w_level, const float* acc_in, float* message, float* acc_out,
+                                              int32_t* topk_tab, float* topk_score, int64_t* topk_idx, int B, int h0, int w0, int h1,
+                                              int w1, int H, int D, int Kp, casmtr_stream_t stream) {
+    const int K = 4 * Kp;
+    if (D != 32 || (h0 & 1) || (w0 & 1) || (h1 & 1) || (w1 & 1) || Kp < 1 || Kp > 32 || topk > K || topk > 16 ||
+        (H != 8 && H != 4 && H != 2 && H != 1) || (long long)(h1 / 2) * (w1 / 2) >= (1 << 22))
+        return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
+    FineQArgs a{};
+    a.q = q; a.key = key; a.value = value; a.parents = parents; a.acc_in = acc_in; a.message = message; a.acc_out = acc_out;
+    a.topk_tab = topk_tab; a.topk_score = topk_score; a.topk_idx = topk_idx; a.temp = temp; a.w_level = w_level; a.topk = topk;
+    a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.H = H; a.Kp = Kp; a.nquads = (h0 / 2) * (w0 / 2); a.lq1 = (h1 / 2) * (w1 / 2);
+    const unsigned d = (unsigned)(w1 / 2);
+    a.div_magic = d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u;
+    hipStream_t s = (hipStream_t)stream;
+    if (topk > 0) return K <= 64 ? launch_fine_quad<1, true>(a, s) : launch_fine_quad<2, true>(a, s);
+    return K <= 64 ? launch_fine_quad<1, false>(a, s) : launch_fine_quad<2, false>(a, s);
+}

@@ -305,15 +305,9 @@ __global__ __launch_bounds__(128, 3) void fine_level_vreg_kernel(const FineVArgs
 template <bool EXACT>
 static int launch_fine_vreg(const FineVArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * 2 * 2912;
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, ncu = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fine_level_vreg_kernel<EXACT>, 128, lds);
-        if (e != hipSuccess || ncu <= 0 || per_cu <= 0) return e != hipSuccess ? (int)e : CASMTR_ERR_UNSUPPORTED;
-        resident = ncu * per_cu / 8 * 8;
-    }
+    static int resident_tab[CASMTR_MAX_DEVICES] = {0};
+    int resident = 0;
+    if (const int r = resident_workgroups(resident_tab, fine_level_vreg_kernel<EXACT>, 128, lds, &resident)) return r;
     const long long work = (long long)a.B * a.nquads * a.H;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;

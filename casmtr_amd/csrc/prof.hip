@@ -31,9 +31,9 @@ using namespace casmtr;
 
 static const char* kNames[CASMTR_PROF_COUNT] = {
     "ds_gemm_kernel", "ds_reduce_kernel", "ds_conf_kernel", "ds_select", "coarse_logits_kernel", "coarse_row_kernel",
-    "coarse_av_kernel", "quad_attn_kernel<fine>", "quad_attn_kernel<cascade>", "window_match_kernel", "nms_select",
+    "coarse_av_kernel", "qta_fine_level[lists<=64]", "quad_attn_kernel<cascade>", "window_match_kernel", "nms_select",
     "nchw_to_tokens_kernel", "window_warp_idx_kernel", "linear_nt_kernel", "token_pool_kernel", "coarse_fused_kernel",
-    "glue(dwconv3x3_tokens, layer_norm)"};
+    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]"};
 
 static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {

@@ -408,7 +408,7 @@ static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quad_attn_kernel<H, KMAX, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    ProfScope ps(MODE == 0 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_CASCADE_ATTN, s);
+    ProfScope ps(MODE == 0 ? (KMAX <= 64 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2) : CASMTR_PROF_CASCADE_ATTN, s);
     hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq * B), dim3(256), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void coarse_logits_kernel(const float* __restr
 //     tolerance and no index depends on it), which makes this pass a pure read of the [B,H,L,S_pad] workspace (122 MB less HBM / Infinity Cache traffic per call at 26x26, B = 8).
 template <int EMAX>
 __global__ __launch_bounds__(256) void coarse_row_kernel(const float* __restrict__ Sg, float* __restrict__ rowstat, float* __restrict__ topk_score,
-                                                         int64_t* __restrict__ topk_idx, int topk, int B, int L, int S,
+                                                         int64_t* __restrict__ topk_idx, int32_t* __restrict__ topk_tab, int topk, int B, int L, int S,
                                                          int Spad, int H) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(const float* __restrict
                 const size_t o = (((size_t)b * L + l) * topk + lane) * H + h;
                 topk_idx[o] = sp;
                 topk_score[o] = expf(ord2f(sk) - m) / s;
+                if (topk_tab) topk_tab[(size_t)rowid * topk + lane] = (int32_t)sp;   // [B,H,L,topk]: the finer level's parents (fine_quad.hip)
             }
             return;
         }
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(256) void coarse_row_kernel(const float* __restrict
                         const size_t o = (((size_t)b * L + l) * topk + t) * H + h;
                         topk_idx[o] = e * 64 + src;
                         topk_score[o] = ps[e];
+                        if (topk_tab) topk_tab[(size_t)rowid * topk + t] = e * 64 + src;
                         key[e] = 0u;
                     }
                 }
@@ -744,15 +746,26 @@ extern "C" size_t casmtr_qta_coarse_level_ws_floats(int B, int L, int S, int H) 
     return (size_t)B * H * L * Spad + 2 * (size_t)B * H * L;   // logits + per-row (max, sum)
 }
 
+extern "C" int casmtr_topk_idx_to_tab(const int64_t* idx, int32_t* tab, int B, int L, int K, int H, casmtr_stream_t stream);
+
 extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const float* v, float temp, int topk,
                                            float w_level, float* logits_ws, float* message, float* acc_out,
                                            float* topk_score, int64_t* topk_idx, int B, int L, int S, int H, int D,
                                            casmtr_stream_t stream) {
+    return casmtr_qta_coarse_level_tab_fwd(q, k, v, temp, topk, w_level, logits_ws, message, acc_out, topk_score, topk_idx, nullptr, B,
+                                           L, S, H, D, stream);
+}
+
+extern "C" int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, const float* v, float temp, int topk,
+                                               float w_level, float* logits_ws, float* message, float* acc_out,
+                                               float* topk_score, int64_t* topk_idx, int32_t* topk_tab, int B, int L, int S, int H,
+                                               int D, casmtr_stream_t stream) {
     if (D != 32 || topk > S) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (coarse_use_fused(S)) {
         const int r = casmtr_qta_coarse_level_fused(q, k, v, temp, topk, w_level, message, acc_out, topk_score, topk_idx, B, L, S, H, s);
+        if (r == 0 && topk_tab) return casmtr_topk_idx_to_tab(topk_idx, topk_tab, B, L, topk, H, stream);
         if (r != CASMTR_ERR_UNSUPPORTED) return r;
     }
     const int Spad = (S + 63) / 64 * 64;
@@ -768,15 +781,15 @@ extern "C" int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const
     const int E = Spad / 64;
     prof_begin(CASMTR_PROF_COARSE_ROW, s);
     if (E <= 4)
-        hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk_tab, topk, B, L, S, Spad, H);
     else if (E <= 8)
-        hipLaunchKernelGGL(coarse_row_kernel<8>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<8>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk_tab, topk, B, L, S, Spad, H);
     else if (E <= 12)
-        hipLaunchKernelGGL(coarse_row_kernel<12>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<12>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk_tab, topk, B, L, S, Spad, H);
     else if (E <= 16)
-        hipLaunchKernelGGL(coarse_row_kernel<16>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<16>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk_tab, topk, B, L, S, Spad, H);
     else if (E <= 32)
-        hipLaunchKernelGGL(coarse_row_kernel<32>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk, B, L, S, Spad, H);
+        hipLaunchKernelGGL(coarse_row_kernel<32>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk_tab, topk, B, L, S, Spad, H);
     else
         return CASMTR_ERR_UNSUPPORTED;
     prof_end(CASMTR_PROF_COARSE_ROW, s);

@@ -290,15 +290,9 @@ static int launch_wm_pos(const float* fq, const float* fk, const int64_t* tp, co
     const float sqrtC = (float)sqrt((double)C);
     const int nquads = (h0 / 2) * (w0 / 2);
     const size_t lds = sizeof(float) * 2 * (4 * C + 2 * 64 + 2 * 2048);
-    static int resident = 0;   // persistent grid: exactly the workgroups that are resident at once
-    if (!resident) {
-        int dev = 0, ncu = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, window_match_pos_kernel<C, RECIP, NP1>, 128, lds);
-        if (e != hipSuccess || ncu <= 0 || per_cu <= 0) return e != hipSuccess ? (int)e : CASMTR_ERR_UNSUPPORTED;
-        resident = ncu * per_cu / 8 * 8;
-    }
+    static int resident_tab[CASMTR_MAX_DEVICES] = {0};   // persistent grid: exactly the workgroups that are resident at once
+    int resident = 0;
+    if (const int r = resident_workgroups(resident_tab, window_match_pos_kernel<C, RECIP, NP1>, 128, lds, &resident)) return r;
     const long long work = (long long)B * nquads;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;

@@ -146,13 +146,55 @@ class QTAttB(nn.Module):
         return cached[1]
 
     def _forward_fused(self, queries, keys, values):
+        n = len(queries)
+        hw_q = [tuple(q.shape[2:]) for q in reversed(queries)]
+        hw_k = [tuple(k.shape[2:]) for k in reversed(keys)]
+        if self._quad_major_ok(hw_q, hw_k):
+            return self._fused_levels_quad(list(zip(reversed(queries), reversed(keys), reversed(values))), hw_q, hw_k)
         # one launch converts all 3 levels x (q,k,v) to token-major rows
         flat = [t.float() for lvl in zip(reversed(queries), reversed(keys), reversed(values)) for t in lvl]
         toks = ops.nchw_to_tokens_multi(flat)
-        n = len(queries)
-        return self._fused_levels([toks[3 * i:3 * i + 3] for i in range(n)],
-                                  [tuple(q.shape[2:]) for q in reversed(queries)],
-                                  [tuple(k.shape[2:]) for k in reversed(keys)])
+        return self._fused_levels([toks[3 * i:3 * i + 3] for i in range(n)], hw_q, hw_k)
+
+    def _quad_major_ok(self, hw_q, hw_k):
+        """The finer levels run on quad-major operands (csrc/fine_quad.hip) whenever their shapes allow it; CASMTR_FINE_KERNEL =
+        dma | quad | vreg keeps the round-2 token-major kernels (tests compare the two)."""
+        import os
+        if os.environ.get("CASMTR_FINE_KERNEL", "qm") != "qm" or len(hw_q) < 2:
+            return False
+        n = len(hw_q)
+        return all(ops.fine_quad_supported(self.nhead, self.dim, hw_q[i], hw_k[i], self.topks[i - 1], self.topks[i] if i < n - 1 else 0)
+                   for i in range(1, n))
+
+    def _fused_levels_quad(self, levels, hw_q, hw_k, want_topk=False):
+        """levels: [(q,k,v)] of [B,C,h,w] tensors, COARSEST first.  Coarsest level token-major (dense attention), every finer level
+        quad-major per head; the top-k lists travel between the levels as compact int32 tables, the reference's int64
+        [B,L,topk,H] tensors (:219-227, internal to the module) are only written when asked for (want_topk: tests)."""
+        n = len(levels)
+        weight = self._level_weights()
+        q0, k0, v0 = ops.nchw_to_tokens_multi([t.float() for t in levels[0]])
+        fine = [t.float() for lvl in levels[1:] for t in lvl]
+        quads = []
+        nchw = [t for t in fine if not ops._is_channels_last(t)]
+        conv = iter(ops.nchw_to_quads_multi(nchw)) if nchw else iter(())
+        for t in fine:   # channels_last tensors are token-major as they stand: one token -> quad pass instead of the NCHW one
+            if ops._is_channels_last(t):
+                B, C, h, w = t.shape
+                quads.append(ops.tokens_to_quads(t.permute(0, 2, 3, 1).reshape(B, h * w, C), h, w))
+            else:
+                quads.append(next(conv))
+        out = ops.qta_coarse_level(q0, k0, v0, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True)
+        acc, tab = out["acc"], out["topk_tab"]
+        per_level = [out]
+        for i in range(1, n):
+            q, k, v = quads[3 * (i - 1):3 * i]
+            topk = self.topks[i] if i < n - 1 else 0   # the reference computes top-k at the finest level too and discards it
+            out = ops.qta_fine_level_quad(q, k, v, tab, hw_q[i], hw_k[i], self.nhead, topk, w_level=weight[i], acc_in=acc,
+                                          want_message=False, want_topk=want_topk)
+            acc, tab = out["acc"], out["topk_tab"]
+            per_level.append(out)
+        self._last_levels = per_level if want_topk else None
+        return acc
 
     def _fused_levels(self, levels, hw_q, hw_k):
         """levels: [(q,k,v)] of token-major [B,L,C] tensors, COARSEST first; hw_q / hw_k the matching grid sizes."""

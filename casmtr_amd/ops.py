@@ -255,8 +255,9 @@ def pola_attn(q, k0, v0, bias_table, H, W, nhead, ws, scale):
     return y
 
 
-def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
-    """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, probs_ws)."""
+def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True, want_tab=False):
+    """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, topk_tab, probs_ws).
+    want_tab: also the compact per-head table [B,H,L,topk] int32 that qta_fine_level_quad takes as `parents`."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
     B, L, Cc = q.shape
     S, D = k.shape[1], Cc // nhead
@@ -266,12 +267,13 @@ def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True):
     acc = torch.empty((B, L, nhead, D), device=q.device, dtype=torch.float32) if w_level is not None else None
     ts = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.float32)
     ti = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.int64)
+    tab = torch.empty((B, nhead, L, topk), device=q.device, dtype=torch.int32) if want_tab else None
     with torch.cuda.device(q.device):
-        _lib.check(l.casmtr_qta_coarse_level_fwd(_ptr(q), _ptr(k), _ptr(v), 1.0 / D ** 0.5, topk,
-                                                 0.0 if w_level is None else float(w_level), _ptr(ws), _ptr(msg),
-                                                 _ptr(acc), _ptr(ts), _ptr(ti), B, L, S, nhead, D, _stream()),
+        _lib.check(l.casmtr_qta_coarse_level_tab_fwd(_ptr(q), _ptr(k), _ptr(v), 1.0 / D ** 0.5, topk,
+                                                     0.0 if w_level is None else float(w_level), _ptr(ws), _ptr(msg),
+                                                     _ptr(acc), _ptr(ts), _ptr(ti), _ptr(tab), B, L, S, nhead, D, _stream()),
                    "qta_coarse_level_fwd")
-    return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti, probs_ws=ws)
+    return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti, topk_tab=tab, probs_ws=ws)
 
 
 def qta_fine_level(q, key, value, prev_idx, hw0, hw1, nhead, topk, w_level=None, acc_in=None, want_message=True):
@@ -291,6 +293,86 @@ def qta_fine_level(q, key, value, prev_idx, hw0, hw1, nhead, topk, w_level=None,
                                                          _ptr(msg), _ptr(acc), _ptr(ts), _ptr(ti), B, h0, w0, h1, w1,
                                                          nhead, D, Kp, _stream()), "qta_fine_level_fwd")
     return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti)
+
+
+def nchw_to_quads_multi(xs):
+    """list of [B,C_i,h_i,w_i] (same B; C_i % 32 == 0, h_i and w_i even) -> list of quad-major per-head tensors
+    [B, C_i/32, (h_i/2)*(w_i/2), 4, 32] (include/casmtr_hip.h), one launch for up to 9 tensors."""
+    import ctypes as C
+    outs = []
+    for j in range(0, len(xs), 9):
+        chunk = [x if x.is_contiguous() else x.contiguous() for x in xs[j:j + 9]]
+        for x in chunk:
+            _chk(x, "x")
+        B = chunk[0].shape[0]
+        if any(x.shape[0] != B for x in chunk):
+            raise RuntimeError("nchw_to_quads_multi: tensors must share the batch size")
+        res = [torch.empty((B, x.shape[1] // 32, (x.shape[2] // 2) * (x.shape[3] // 2), 4, 32), device=x.device, dtype=torch.float32)
+               for x in chunk]
+        n = len(chunk)
+        arr = lambda vals, ty: C.cast((ty * n)(*vals), C.c_void_p)
+        with torch.cuda.device(chunk[0].device):
+            _lib.check(_lib.lib().casmtr_nchw_to_quads_multi(arr([x.data_ptr() for x in chunk], C.c_void_p),
+                                                             arr([r.data_ptr() for r in res], C.c_void_p),
+                                                             arr([x.shape[1] for x in chunk], C.c_int), arr([x.shape[2] for x in chunk], C.c_int),
+                                                             arr([x.shape[3] for x in chunk], C.c_int), n, B, _stream()),
+                       "nchw_to_quads_multi")
+        outs += res
+    return outs
+
+
+def tokens_to_quads(x, h, w):
+    """token-major [B,h*w,C] -> quad-major per head [B,C/32,(h/2)*(w/2),4,32]"""
+    _chk(x, "x")
+    B, L, Cc = x.shape
+    if L != h * w:
+        raise RuntimeError("tokens_to_quads: x must be [B, h*w, C]")
+    out = torch.empty((B, Cc // 32, (h // 2) * (w // 2), 4, 32), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().casmtr_tokens_to_quads(_ptr(x), _ptr(out), B, Cc, h, w, _stream()), "tokens_to_quads")
+    return out
+
+
+def topk_idx_to_tab(idx):
+    """[B,L,K,H] int64 (the reference's topk_idx) -> [B,H,L,K] int32 (the `parents` table of qta_fine_level_quad)"""
+    _chk(idx, "idx", torch.int64)
+    B, L, K, H = idx.shape
+    tab = torch.empty((B, H, L, K), device=idx.device, dtype=torch.int32)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.lib().casmtr_topk_idx_to_tab(_ptr(idx), _ptr(tab), B, L, K, H, _stream()), "topk_idx_to_tab")
+    return tab
+
+
+def fine_quad_supported(nhead, head_dim, hw0, hw1, Kp, topk):
+    """shapes the quad-major fine-level kernel covers (csrc/fine_quad.hip); anything else runs the token-major kernels"""
+    return (head_dim == 32 and nhead in (1, 2, 4, 8) and all(v % 2 == 0 and v > 0 for v in (*hw0, *hw1)) and 1 <= Kp <= 32
+            and topk <= 16 and topk <= 4 * Kp and (hw1[0] // 2) * (hw1[1] // 2) < (1 << 22))
+
+
+def qta_fine_level_quad(q, key, value, parents, hw0, hw1, nhead, topk, w_level=None, acc_in=None, want_message=True,
+                        want_topk=True, want_tab=None):
+    """QTAttB.process_fine_level on quad-major operands: q [B,H,Lq0,4,32], key/value [B,H,Lq1,4,32], parents [B,H,Lq0,Kp] int32
+    -> dict(message, acc [B,L,H,D] raster; topk_score, topk_idx [B,L,topk,H] (want_topk); topk_tab [B,H,L,topk] int32 (want_tab,
+    default: whenever topk > 0))."""
+    _chk(q, "q"), _chk(key, "key"), _chk(value, "value"), _chk(parents, "parents", torch.int32), _chk(acc_in, "acc_in")
+    (h0, w0), (h1, w1) = hw0, hw1
+    B, H, Lq0 = q.shape[:3]
+    L, D, Kp = h0 * w0, 32, parents.shape[3]
+    if H != nhead or Lq0 * 4 != L or tuple(key.shape[:3]) != (B, H, (h1 // 2) * (w1 // 2)) or tuple(parents.shape[:3]) != (B, H, Lq0):
+        raise RuntimeError("qta_fine_level_quad: operands must be quad-major [B,H,Lq,4,32] with parents [B,H,Lq0,Kp]")
+    dev = q.device
+    want_tab = (topk > 0) if want_tab is None else (want_tab and topk > 0)
+    msg = torch.empty((B, L, nhead, D), device=dev, dtype=torch.float32) if want_message else None
+    acc = torch.empty((B, L, nhead, D), device=dev, dtype=torch.float32) if w_level is not None else None
+    ts = torch.empty((B, L, topk, nhead), device=dev, dtype=torch.float32) if topk > 0 and want_topk else None
+    ti = torch.empty((B, L, topk, nhead), device=dev, dtype=torch.int64) if topk > 0 and want_topk else None
+    tab = torch.empty((B, nhead, L, topk), device=dev, dtype=torch.int32) if want_tab else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().casmtr_qta_fine_level_quad_fwd(_ptr(q), _ptr(key), _ptr(value), _ptr(parents), 1.0 / D ** 0.5, topk,
+                                                              0.0 if w_level is None else float(w_level), _ptr(acc_in), _ptr(msg),
+                                                              _ptr(acc), _ptr(tab), _ptr(ts), _ptr(ti), B, h0, w0, h1, w1, nhead, D,
+                                                              Kp, _stream()), "qta_fine_level_quad_fwd")
+    return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti, topk_tab=tab)
 
 
 def cascade_attn(q, key, value, topk_pos, hw0, hw1, nhead, dilated=1, rel_pos=None, want_idx=True):

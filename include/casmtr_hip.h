@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 2
+#define CASMTR_ABI_VERSION 3
 int casmtr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -89,6 +89,35 @@ int casmtr_qta_fine_level_fwd(const float* q, const float* key, const float* val
                               float temp, int topk, float w_level, const float* acc_in, float* message,
                               float* acc_out, float* topk_score, int64_t* topk_idx,
                               int B, int h0, int w0, int h1, int w1, int H, int D, int Kp, casmtr_stream_t stream);
+
+/* ---- the same level on QUAD-MAJOR operands (round 3; what QTAttB's fused path runs by default) ----------------------------------
+ * Quad-major per head: x_qm[b][hd][Q][c][d] with Q = (r/2)*(w/2) + (col/2) the quad of token (r, col) of an h x w grid (h, w even),
+ * c = (r&1)*2 + (col&1) its child slot (the reference's "(t1 t2)" order, :188-199), d < 32.  The 4 children of a parent selected at the
+ * previous level are one contiguous 512-byte run, a (pair, head) slice is contiguous.
+ *
+ * casmtr_nchw_to_quads_multi: src_i [B, C_i, h_i, w_i] (the module's NCHW pyramids) -> dst_i [B, C_i/32, (h_i/2)*(w_i/2), 4, 32];
+ *   the `rearrange(...)` calls of :165-167,185-189 folded into one layout pass.  src/dst/C/h/w: HOST arrays of length n <= 9.          */
+int casmtr_nchw_to_quads_multi(const float* const* src, float* const* dst, const int* C, const int* h, const int* w, int n, int B,
+                               casmtr_stream_t stream);
+/* token-major [B, h*w, C] -> quad-major (the callers' / tests' entry into the layout)                                                 */
+int casmtr_tokens_to_quads(const float* x, float* out, int B, int C, int h, int w, casmtr_stream_t stream);
+/* [B,L,K,H] int64 (the reference's topk_idx layout) -> compact per-head table [B,H,L,K] int32                                          */
+int casmtr_topk_idx_to_tab(const int64_t* idx, int32_t* tab, int B, int L, int K, int H, casmtr_stream_t stream);
+
+/* QTAttB.process_fine_level on quad-major q [B,H,Lq0,4,32], key/value [B,H,Lq1,4,32] (Lq = quads of the h x w grid);
+ *   parents [B,H,Lq0,Kp] int32: the previous level's top-k (absolute index on ITS key grid = quad index on this level's key grid);
+ *   acc_in nullable [B,Lq0,H*32]; message / acc_out nullable [B,h0*w0,H*32] TOKEN-major raster (what the module returns);
+ *   topk_tab nullable [B,H,h0*w0,topk] int32 (this level's top-k as the next level's `parents`); topk_score / topk_idx nullable
+ *   [B,h0*w0,topk,H] (the reference's tensors, :219-227, on request).  Kp <= 32, topk <= 16, H in {1,2,4,8}; anything else is
+ *   CASMTR_ERR_UNSUPPORTED and the caller uses the token-major entry point above.  Same results as casmtr_qta_fine_level_fwd.        */
+int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, const float* value, const int32_t* parents, float temp,
+                                   int topk, float w_level, const float* acc_in, float* message, float* acc_out,
+                                   int32_t* topk_tab, float* topk_score, int64_t* topk_idx, int B, int h0, int w0, int h1,
+                                   int w1, int H, int D, int Kp, casmtr_stream_t stream);
+/* casmtr_qta_coarse_level_fwd with one more output: topk_tab nullable [B,H,L,topk] int32 (the finer level's `parents`)               */
+int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, const float* v, float temp, int topk, float w_level,
+                                    float* logits_ws, float* message, float* acc_out, float* topk_score,
+                                    int64_t* topk_idx, int32_t* topk_tab, int B, int L, int S, int H, int D, casmtr_stream_t stream);
 
 /* CascadeQTAttB.forward (modules/quadtree_attention.py:400-452).
  *   q [B,h0*w0,C]; key/value [B,h1*w1,C]; topk_pos [B,(h0/2)*(w0/2),KW,2] (row,col) on the (h1/2)x(w1/2) grid;
@@ -221,7 +250,7 @@ enum {
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
     CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED,
-    CASMTR_PROF_GLUE, CASMTR_PROF_COUNT
+    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
 /* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).

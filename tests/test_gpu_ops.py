@@ -97,7 +97,35 @@ def _tok(x):
     return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(B, h * w, C))
 
 
-@pytest.mark.parametrize("kernel", ["vreg", "dma", "quad"])
+def _fine_level(ops, kernel, q, k, v, prev, hw0, hw1, H, topk, **kw):
+    """kernel 'qm': the round-3 quad-major kernel (operands re-laid-out on the GPU, previous top-k as the compact int32 table);
+    otherwise the token-major entry point with CASMTR_FINE_KERNEL = kernel"""
+    if kernel != "qm":
+        return ops.qta_fine_level(q, k, v, prev, hw0, hw1, H, topk, **kw)
+    return ops.qta_fine_level_quad(ops.tokens_to_quads(q, *hw0), ops.tokens_to_quads(k, *hw1), ops.tokens_to_quads(v, *hw1),
+                                   ops.topk_idx_to_tab(prev), hw0, hw1, H, topk, **kw)
+
+
+def test_quad_major_layout_passes(ops):
+    """NCHW -> quad-major, tokens -> quad-major and the int64 -> int32 table transposition are pure data movement"""
+    r = np.random.default_rng(5)
+    shapes = [(2, 64, 12, 20), (2, 256, 6, 70), (2, 32, 2, 2), (2, 128, 26, 26)]
+    xs = [r.standard_normal(sh).astype(np.float32) for sh in shapes]
+
+    def ref(x):
+        B, C, h, w = x.shape
+        y = x.reshape(B, C // 32, 32, h // 2, 2, w // 2, 2).transpose(0, 1, 3, 5, 4, 6, 2)   # b hd qy qx r c d
+        return np.ascontiguousarray(y).reshape(B, C // 32, (h // 2) * (w // 2), 4, 32)
+    outs = ops.nchw_to_quads_multi([T(x) for x in xs])
+    for x, o in zip(xs, outs):
+        assert np.array_equal(N(o), ref(x))
+        B, C, h, w = x.shape
+        assert np.array_equal(N(ops.tokens_to_quads(T(_tok(x)), h, w)), ref(x))
+    idx = r.integers(0, 1000, (3, 17, 5, 4)).astype(np.int64)
+    assert np.array_equal(N(ops.topk_idx_to_tab(T(idx))), idx.transpose(0, 3, 1, 2).astype(np.int32))
+
+
+@pytest.mark.parametrize("kernel", ["qm", "vreg", "dma", "quad"])
 @pytest.mark.parametrize("name", list(CASES["qtattb"]))
 def test_qtattb_levels(ops, monkeypatch, name, kernel):
     """coarse + fine level kernels chained exactly like QTAttB.forward; indices bit-exact vs oracle AND vs the reference."""
@@ -117,7 +145,7 @@ def test_qtattb_levels(ops, monkeypatch, name, kernel):
         if i == 0:
             out = ops.qta_coarse_level(T(q), T(k), T(v), H, topks[0], w_level=float(wsm[0]))
         else:
-            out = ops.qta_fine_level(T(q), T(k), T(v), prev, (h0, w0), (h1, w1), H, topks[i], w_level=float(wsm[i]), acc_in=acc)
+            out = _fine_level(ops, kernel, T(q), T(k), T(v), prev, (h0, w0), (h1, w1), H, topks[i], w_level=float(wsm[i]), acc_in=acc)
         acc, prev = out["acc"], out["topk_idx"]
         assert np.array_equal(N(out["topk_idx"]), lv_o[i]["topk_idx"]), f"level {i} top-k indices differ from the oracle"
         assert np.array_equal(N(out["topk_idx"]), g[f"L{i}_topk_idx"].astype(np.int64)), f"level {i} top-k differ from the reference"
@@ -283,12 +311,14 @@ def test_fine_level_wide_candidate_lists(ops, H, Kp, topk):
 
 @pytest.mark.parametrize("H,Kp,topk,with_acc", [(8, 16, 8, True), (8, 32, 16, True), (8, 16, 0, True), (4, 32, 16, False), (2, 9, 5, True),
                                                  (1, 16, 4, True), (4, 5, 20, True), (8, 1, 4, True), (2, 13, 0, False)])
-@pytest.mark.parametrize("kernel", ["vreg", "dma"])
+@pytest.mark.parametrize("kernel", ["qm", "vreg", "dma"])
 def test_fine_level_dma_kernel_shapes(ops, monkeypatch, kernel, H, Kp, topk, with_acc):
     """fine_level_vreg_kernel (K = 4*Kp <= 64; longer lists fall through) and fine_level_dma_kernel (K <= 128): every head count /
     XCD split, ragged candidate counts, top-k == K, no top-k (finest level), no incoming accumulator, query grid != key grid,
     several pairs -- top-k bit-exact, messages within tolerance"""
     monkeypatch.setenv("CASMTR_FINE_KERNEL", kernel)
+    if kernel == "qm" and topk > 16:
+        pytest.skip("the quad-major kernel keeps the 16 best (every shipped config); longer lists run the token-major kernels")
     r = np.random.default_rng(1000 * H + 10 * Kp + topk)
     B, (h0, w0), (h1, w1) = 3, (12, 20), (16, 12)
     C = H * 32
@@ -300,12 +330,47 @@ def test_fine_level_dma_kernel_shapes(ops, monkeypatch, kernel, H, Kp, topk, wit
     acc_in = r.standard_normal((B, Lq, H, 32)).astype(np.float32) if with_acc else None
     o = oracle.qta_fine_level(q.reshape(B, -1, H, 32), k.reshape(B, -1, H, 32), v.reshape(B, -1, H, 32), prev, (h0, w0), (h1, w1),
                               topk, 0.37, acc_in)
-    out = ops.qta_fine_level(T(q), T(k), T(v), T(prev.astype(np.int64)), (h0, w0), (h1, w1), H, topk, w_level=0.37,
-                             acc_in=None if acc_in is None else T(acc_in))
+    out = _fine_level(ops, kernel, T(q), T(k), T(v), T(prev.astype(np.int64)), (h0, w0), (h1, w1), H, topk, w_level=0.37,
+                      acc_in=None if acc_in is None else T(acc_in))
     if topk:
         assert np.array_equal(N(out["topk_idx"]), o["topk_idx"])
         assert_close(N(out["topk_score"]), o["topk_score"], SOFTMAX_TOL, "topk_score")
+        if kernel == "qm":   # the compact table the next level reads holds the same indices
+            assert np.array_equal(N(out["topk_tab"]), o["topk_idx"].transpose(0, 3, 1, 2).astype(np.int32))
     assert_close(N(out["message"]), o["message"], SOFTMAX_TOL, "message")
+    assert_close(N(out["acc"]), o["acc"], SOFTMAX_TOL, "merged message")
+
+
+@pytest.mark.parametrize("kind", ["duplicate_rows", "near_ties", "all_equal", "one_bucket"])
+@pytest.mark.parametrize("Kp,topk", [(32, 16), (16, 8), (7, 16)])
+def test_fine_quad_selection_ties(ops, kind, Kp, topk):
+    """The quad-major kernel selects on packed 32-bit keys (25 high bits of the ordered logit | position) and must fall back to the
+    exact iterated argmax whenever two of the best logits share those bits: exact ties (identical key rows: first position wins, as
+    torch.topk on the oracle's order), logits a few ulp apart, everything equal, all logits inside one 128-ulp bucket."""
+    r = np.random.default_rng(sum(map(ord, kind)) * 1000 + 10 * Kp + topk)
+    B, H, (h0, w0), (h1, w1) = 2, 4, (8, 12), (16, 16)
+    C = H * 32
+    q = r.standard_normal((B, h0 * w0, C)).astype(np.float32)
+    k = r.standard_normal((B, h1 * w1, C)).astype(np.float32)
+    v = r.standard_normal((B, h1 * w1, C)).astype(np.float32)
+    if kind == "duplicate_rows":      # many identical key rows -> exact ties among the candidates
+        k = k.reshape(B, -1, H, 32); k[:, 1::2] = k[:, 0::2]; k[:, 5::8] = k[:, 0:1]; k = k.reshape(B, -1, C)
+    elif kind == "near_ties":         # rows that differ in the last bits only
+        k = k.reshape(B, -1, H, 32); base = k[:, :1].copy()
+        k[:] = base * (1.0 + 1e-7 * r.integers(-3, 4, (B, h1 * w1, H, 1)).astype(np.float32)); k = k.reshape(B, -1, C)
+    elif kind == "all_equal":
+        k[:] = k[:, :1]
+    elif kind == "one_bucket":        # tiny keys: every logit lies within a few ulp of a constant set by one large channel
+        k = (1e-6 * k).reshape(B, -1, H, 32); k[..., 0] = 1.0; k = k.reshape(B, -1, C)
+        q = q.reshape(B, -1, H, 32); q[..., 0] = 3.0; q = q.reshape(B, -1, C)
+    Lq, Sp = (h0 // 2) * (w0 // 2), (h1 // 2) * (w1 // 2)
+    prev = np.stack([np.stack([r.permutation(Sp)[:Kp] for _ in range(H)], -1) for _ in range(B * Lq)]).reshape(B, Lq, Kp, H)
+    tk = min(topk, 4 * Kp)
+    o = oracle.qta_fine_level(q.reshape(B, -1, H, 32), k.reshape(B, -1, H, 32), v.reshape(B, -1, H, 32), prev, (h0, w0), (h1, w1),
+                              tk, 0.5, None)
+    out = _fine_level(ops, "qm", T(q), T(k), T(v), T(prev.astype(np.int64)), (h0, w0), (h1, w1), H, tk, w_level=0.5)
+    assert np.array_equal(N(out["topk_idx"]), o["topk_idx"]), f"{kind}: top-k indices"
+    assert_close(N(out["topk_score"]), o["topk_score"], SOFTMAX_TOL, "topk_score")
     assert_close(N(out["acc"]), o["acc"], SOFTMAX_TOL, "merged message")
 
 

@@ -189,6 +189,15 @@ def test_full_size_chain_vs_oracle(masked):
              ops.qta_fine_level(q, k, v, prev, hw, hw, cfg.coarse_heads, cfg.coarse_topks[i]))
         prev = o["topk_idx"]
         levels_gpu.append(o)
+    # the same call through the module's default path: finer levels on quad-major operands (csrc/fine_quad.hip), top-k lists
+    # as compact int32 tables between the levels; the reference's int64 tensors materialised for this comparison only
+    lv_nchw = [(inp["cq0"][1][lv], inp["ck1"][1][lv], inp["cv1"][1][lv]) for lv in (2, 1, 0)]
+    hws = [tuple(t[0].shape[2:]) for t in lv_nchw]
+    assert model.qta._quad_major_ok(hws, hws), "the headline shapes must run the quad-major kernel"
+    with torch.no_grad():
+        final_qm = model.qta._fused_levels_quad(lv_nchw, hws, hws, want_topk=True)
+    levels_qm = model.qta._last_levels
+    assert torch.equal(final_qm, out["messages"][2]), "materialising the top-k tensors must not change the message"
     for e in (0, B - 1):
         n = lambda t: N(t[e:e + 1])
         fo, lv = oracle.qtattb_forward([n(x) for x in inp["cq0"][1]], [n(x) for x in inp["ck1"][1]], [n(x) for x in inp["cv1"][1]],
@@ -196,6 +205,10 @@ def test_full_size_chain_vs_oracle(masked):
         for i, side in enumerate((26, 52, 104)):
             assert np.array_equal(n(levels_gpu[i]["topk_idx"]), lv[i]["topk_idx"]), f"pair {e}: top-k indices at {side}x{side}"
             assert_close(n(levels_gpu[i]["topk_score"]), lv[i]["topk_score"], TOL, f"pair {e}: top-k scores at {side}x{side}")
+            if i < 2:   # (the module skips the finest level's top-k, which the reference computes and discards)
+                assert np.array_equal(n(levels_qm[i]["topk_idx"]), lv[i]["topk_idx"]), f"pair {e}: quad-major path, top-k at {side}x{side}"
+                assert np.array_equal(n(levels_qm[i]["topk_tab"]), lv[i]["topk_idx"].transpose(0, 3, 1, 2)), f"pair {e}: int32 table at {side}x{side}"
+                assert_close(n(levels_qm[i]["topk_score"]), lv[i]["topk_score"], TOL, f"pair {e}: quad-major top-k scores at {side}x{side}")
         assert_close(n(out["messages"][2]), fo, TOL, f"pair {e}: QTAttB cross message (104x104)")
         # coarse matching
         mk = (lambda lvl, im: n(inp[f"mask_{lvl}{im}"]).reshape(1, -1)) if masked else (lambda lvl, im: None)
@@ -405,7 +418,7 @@ def test_full_size_pairs_are_independent_of_their_batch():
                 assert torch.equal(sub[f"{lvl}.{k}"][m_sub], full[f"{lvl}.{k}"][m_full]), f"{lvl}.{k} of pair {old_b}"
 
 
-@pytest.mark.parametrize("env", [{"CASMTR_FINE_KERNEL": "quad"}, {"CASMTR_FINE_KERNEL": "vreg"}, {"CASMTR_CASCADE_KERNEL": "quad"},
+@pytest.mark.parametrize("env", [{"CASMTR_FINE_KERNEL": "dma"}, {"CASMTR_FINE_KERNEL": "quad"}, {"CASMTR_FINE_KERNEL": "vreg"}, {"CASMTR_CASCADE_KERNEL": "quad"},
                                  {"CASMTR_WINDOW_KERNEL": "quad"}, {"CASMTR_COARSE_KERNEL": "fused"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}={v}" for k, v in e.items()))
 def test_full_size_kernel_variants_agree(monkeypatch, env):
