@@ -335,6 +335,99 @@ def test_indoor_shapes_vs_oracle():
     assert_close(N(msg), mo, TOL, "indoor cascade message with rel_pos (160x120)")
 
 
+def _audit_match_list_diff(got, want, conf_g, conf_o, hw, st, pre_g, what, eps=2e-5):
+    """got / want: sets of (i, j) of one pair at one stage (GPU chain vs the independent oracle chain).  The index tensors feeding
+    the selection are asserted EQUAL by the caller, so the two lists can only differ where a float comparison sits within the
+    softmax tolerance of its threshold: conf vs test_thr, a previous stage's conf vs pre_thr, or two confidences of one NMS
+    window within eps of each other (the reference's max-pool winner then depends on the last bits of expf).  Every differing
+    entry must show one of those causes."""
+    h, w = hw
+    cg, co = conf_g.reshape(h, w), conf_o.reshape(h, w)
+    for i, j in sorted(got ^ want):
+        y, x = divmod(i, w)
+        why = []
+        if min(abs(cg[y, x] - st.test_thr), abs(co[y, x] - st.test_thr)) <= eps:
+            why.append("conf ~ test_thr")
+        for (pc, (ph, pw)), thr in zip(pre_g, st.pre_thr):
+            v = pc.reshape(ph, pw)[y * ph // h, x * pw // w]
+            if abs(v - thr) <= eps:
+                why.append("previous-stage conf ~ pre_thr")
+        if st.nms_window:
+            r = st.nms_window // 2
+            win = co[max(y - r, 0):y + r + 1, max(x - r, 0):x + r + 1]
+            if (np.abs(win - co[y, x]) <= eps).sum() > 1 and co[y, x] >= win.max() - eps:
+                why.append("NMS window near-tie")
+        assert why, f"{what}: match ({i}, {j}) differs between the GPU chain and the oracle chain without a borderline cause"
+    return len(got ^ want)
+
+
+@pytest.mark.parametrize("which", ["2c", "indoor"])
+def test_named_config_chain_vs_oracle(which):
+    """BASELINE configs[3] (CasMTR-2c: 4c stage without NMS and border_rm 1, then the 2c stage with pre_level ['8c','4c'], NMS,
+    cascade_model_stage4.py:150-195) and configs[4] shapes (indoor 640x480: topks [32,16,16], 8 coarse layers, rel_pos, no NMS) as
+    whole chains with the SHIPPED thresholds, B = 2, first and last pair: every index output equals the oracle chain's, values
+    within 1e-4, match lists exact given the GPU's own confidences and audited against the independent oracle chain."""
+    from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
+    from oracle.chain import run_chain
+    B = 2
+    cfg = HotPathConfig.named(which)                                  # implicit windows: the shipped data flow
+    cfg_e = HotPathConfig.named(which, implicit_windows=False)        # the reference's int64 window tensors, for the index check
+    inp = make_synthetic_inputs(cfg, B, DEV, seed=23)
+    outs = []
+    with torch.no_grad():
+        for c in (cfg, cfg_e):
+            m = HotPath(c).to(DEV)
+            m.qta.weight.copy_(inp["weight"])
+            outs.append(m(inp))
+        torch.cuda.synchronize()
+        out, out_e = outs
+        # per-level top-k of the first cross call through the module's own (quad-major) path
+        lv_nchw = [(inp["cq0"][1][lv], inp["ck1"][1][lv], inp["cv1"][1][lv]) for lv in (2, 1, 0)]
+        hws = [tuple(t[0].shape[2:]) for t in lv_nchw]
+        assert m.qta._quad_major_ok(hws, hws)
+        m.qta._fused_levels_quad(lv_nchw, hws, hws, want_topk=True)
+        levels_qm = m.qta._last_levels
+    for lvl in [st.level for st in cfg.stages]:
+        for k in ("next_idx_c01", "next_idx_c10", "next_conf_c01", "b_ids", "i_ids", "j_ids", "mconf"):
+            assert torch.equal(out["data"][f"stage_{lvl}"][k], out_e["data"][f"stage_{lvl}"][k]), f"implicit vs explicit windows: stage_{lvl}[{k}]"
+    n_calls = 2 * cfg.coarse_layers
+    for e in (0, B - 1):
+        n = lambda t: N(t[e:e + 1])
+        o = run_chain(cfg, inp, pair=e, qta_calls=(0, 2, n_calls - 1))
+        for call, (fo, lv) in o["qta"].items():
+            assert_close(n(out["messages"][call]), fo, TOL, f"pair {e}: QTAttB call {call}")
+        for i in range(2):
+            assert np.array_equal(n(levels_qm[i]["topk_idx"]), o["qta"][2][1][i]["topk_idx"]), f"pair {e}: QTAttB top-k at level {i}"
+        st8, d8 = out["data"]["stage_8c"], o["d8"]
+        assert np.array_equal(n(st8["next_idx_c01"]), d8["next_idx_c01"]) and np.array_equal(n(st8["next_idx_c10"]), d8["next_idx_c10"])
+        assert_close(n(st8["next_conf_c01"]), d8["next_conf_c01"], TOL, "coarse next_conf")
+        pre_g = [(n(st8["next_conf_c01"]), cfg.hw8)]
+        mi = n_calls
+        for st in cfg.stages:
+            lvl, hw = st.level, cfg.hw(st.div)
+            g, ge, so = out["data"][f"stage_{lvl}"], out_e["data"][f"stage_{lvl}"], o["stages"][lvl]
+            assert np.array_equal(n(ge["idx_c01"]), so["i01"]) and np.array_equal(n(ge["idx_c10"]), so["i10"]), f"pair {e}: {lvl} window indices"
+            for j, mo in enumerate(so["msgs"]):
+                assert_close(n(out["messages"][mi + j]).reshape(mo.shape), mo, TOL, f"pair {e}: {lvl} CascadeQTAttB message {j}")
+            mi += len(so["msgs"])
+            assert np.array_equal(n(g["next_idx_c01"]), so["m01"]["next_idx"]), f"pair {e}: {lvl} window argmax 0->1"
+            assert np.array_equal(n(g["next_idx_c10"]), so["m10"]["next_idx"]), f"pair {e}: {lvl} window argmax 1->0"
+            assert_close(n(g["conf_matrix"]), so["m01"]["conf_matrix"], TOL, f"{lvl} conf_matrix")
+            # (1) the selection itself, given the GPU's own confidences: exact
+            sel_g = oracle.nms_select(n(g["next_conf_c01"]), so["m01"]["next_idx"], so["m10"]["next_idx"], hw, hw, st.nms_window, st.test_thr,
+                                      [(pc, phw, thr) for (pc, phw), thr in zip(pre_g, st.pre_thr)], st.border_rm)
+            mine = N(g["b_ids"]) == e
+            assert np.array_equal(N(g["i_ids"])[mine], sel_g["i_ids"]) and np.array_equal(N(g["j_ids"])[mine], sel_g["j_ids"]), \
+                f"pair {e}: {lvl} match list (thresholds {st.test_thr} / {st.pre_thr}, border_rm {st.border_rm}, NMS {st.nms_window}, double check)"
+            assert mine.sum() > 50
+            # (2) against the independent oracle chain (its own softmax values): differences only at borderline comparisons
+            got = set(zip(N(g["i_ids"])[mine].tolist(), N(g["j_ids"])[mine].tolist()))
+            want = set(zip(so["sel"]["i_ids"].tolist(), so["sel"]["j_ids"].tolist()))
+            nd = _audit_match_list_diff(got, want, n(g["next_conf_c01"]), so["m01"]["next_conf"], hw, st, pre_g, f"pair {e}, stage {lvl}")
+            assert nd <= max(2, len(want) // 500)
+            pre_g.append((n(g["next_conf_c01"]), hw))
+
+
 @pytest.mark.parametrize("name", list(CASES["qtatt_variants"]))
 def test_qtatt_variants_vs_reference(name):
     """QTAttA and QTAttGuided (no shipped config selects them) against the reference python."""
