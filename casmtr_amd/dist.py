@@ -113,3 +113,29 @@ def gather_matches(out, pairs_per_rank=None, dst: int = 0, pair_offset=None):
     dist.gather(pad_mk, None, dst=dst)
     dist.gather(pad_b, None, dst=dst)
     return None
+
+
+class MatchGatherer:
+    """gather_matches() every `every` steps instead of every step: the lists of the steps in between stay on their rank (device
+    tensors, tens of KB each) and travel in ONE exchange -- one counts all-gather, one host read-back and two padded gathers per
+    `every` steps.  Pair ids in the gathered m_bids are step * pairs_per_step + global pair id, steps counted from the last flush.
+    every = 1 is the reference's behaviour (results leave the rank after every batch).  Single process: plain passthrough."""
+
+    def __init__(self, every=1, pair_offset=0, pairs_per_step=0, dst=0):
+        self.every, self.pair_offset, self.pairs_per_step, self.dst = max(1, int(every)), int(pair_offset), int(pairs_per_step), dst
+        self._held = []
+
+    def add(self, out):
+        """-> what gather_matches returns when this call triggered an exchange (rank dst: dict, others: None), else None"""
+        if not is_dist() or self.every == 1:
+            return gather_matches(out, dst=self.dst, pair_offset=self.pair_offset)
+        self._held.append({k: out[k] for k in ("m_bids", "mkpts0", "mkpts1", "mconf")})
+        return self.flush() if len(self._held) >= self.every else None
+
+    def flush(self):
+        if not self._held:
+            return None
+        held, self._held = self._held, []
+        both = {k: torch.cat([h[k] for h in held]) for k in ("mkpts0", "mkpts1", "mconf")}
+        both["m_bids"] = torch.cat([h["m_bids"] + i * self.pairs_per_step for i, h in enumerate(held)])
+        return gather_matches(both, dst=self.dst, pair_offset=self.pair_offset)

@@ -13,9 +13,11 @@ arithmetic of each block):
     fine_preprocess / loftr_fine / fine_matching                         src/model/functions/fine_matching.py:14-140, transformer.py:97-139
     forward           the glue of cascade_model_stage3.py:104-178
 The cascade stage hands its window lists to the matcher in their implicit form (ops.WindowIndex): the int64 upsampled_idx the
-reference builds in every cross layer is never materialised.
+reference builds in every cross layer is never materialised (the matchers are built with materialize_idx=False;
+data['stage_*']['idx_c01'].materialize() rebuilds it on request).
 """
 import math
+import threading
 
 import torch
 import torch.nn as nn
@@ -45,7 +47,18 @@ def outdoor_4c_config():
 # GEMMs: the reference's test.py evaluates under fp16 autocast (pl.Trainer(precision=16), lightning_cascade.py:352).  QuadTree /
 # cascade attention with their q/k/v projections, the matchers, LayerNorm and softmax stay fp32; outputs are cast back to fp32.
 # Off by default (parity tests run fp32 throughout).
-_CONV_DTYPE = [None]
+class _ThreadLocalSlot(threading.local):
+    """`slot[0]` per thread: two models with different glue precisions may run from different host threads (two-stream drivers)"""
+    value = None
+
+    def __getitem__(self, i):
+        return self.value
+
+    def __setitem__(self, i, v):
+        self.value = v
+
+
+_CONV_DTYPE = _ThreadLocalSlot()
 
 
 def _cv(module, x):
@@ -57,8 +70,10 @@ def _cv(module, x):
 
 
 def _fast(x):
-    """inference on the GPU: the token-major HIP element kernels apply (otherwise the same arithmetic on torch ops)"""
-    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+    """inference on the GPU: the token-major HIP element kernels apply (otherwise the same arithmetic on torch ops).  They have no
+    backward, so they are used only with autograd off (forward() runs under no_grad; a submodule called directly with grad enabled
+    takes the torch ops and its parameters receive gradients)"""
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
 def _tokens(f):
@@ -174,16 +189,21 @@ class _WindowAttention(nn.Module):
     def forward(self, x, H, W):
         B, N, C = x.shape
         ws, nh = self.ws, self.heads
-        if _fast(x) and ws == 7 and C // nh == 32:   # one kernel on the un-padded tokens; no mask, no attention matrix in HBM
-            return _lin(self.proj, ops.window_attn(_lin(self.qkv, x), H, W, nh, ws, self.scale))
         pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+        # Reference quirk, reproduced: forward_mask builds the padding mask with `mask[:, -pad_b:, :].fill_(1)` and
+        # `mask[:, :, -pad_r:].fill_(1)` (cascade_attention.py:135-137); a zero pad makes `-0:` select the whole mask, so when exactly
+        # ONE grid side is a multiple of ws the mask is all ones, attn_mask is 0 everywhere and real queries also attend to the
+        # zero-padded keys (k = v = the qkv bias).  Image sides that are multiples of 224 in one direction only (448x640, ...).
+        unmasked_padding = (pr == 0) != (pb == 0)
+        if _fast(x) and ws == 7 and C // nh == 32 and not unmasked_padding:   # one kernel on the un-padded tokens; no mask, no attention matrix in HBM
+            return _lin(self.proj, ops.window_attn(_lin(self.qkv, x), H, W, nh, ws, self.scale))
         x = F.pad(x.view(B, H, W, C), (0, 0, 0, pr, 0, pb))
         Hp, Wp = H + pb, W + pr
         gh, gw = Hp // ws, Wp // ws
         pad = torch.zeros((1, Hp, Wp), device=x.device)
-        if pb:
+        if pb and not unmasked_padding:
             pad[:, -pb:, :] = 1
-        if pr:
+        if pr and not unmasked_padding:
             pad[:, :, -pr:] = 1
         pad = pad.reshape(1, gh, ws, gw, ws).transpose(2, 3).reshape(1, gh * gw, ws * ws)
         bias = pad.unsqueeze(2) - pad.unsqueeze(3)                        # != 0 where exactly one of (query, key) is padding
@@ -543,12 +563,12 @@ class CasMTR4c(nn.Module):
         self.up_block1 = UpBlock(b[2], b[1])
         self.loftr_coarse_4c = CascadeTransformer(c["coarse2"])
         cas = lambda cc: {"propagation": "window", "dilated": cc.get("dilated", 1), "post_config": cc["post_config"]}
-        self.cascade_matching_4c = CascadeMatching(c["match_cascade"], cas(c["coarse2"]), stage="4c")
+        self.cascade_matching_4c = CascadeMatching(c["match_cascade"], cas(c["coarse2"]), stage="4c", materialize_idx=False)
         if self.has_2c:
             self.pos_encoding_2c = SinePositionEncoding(b[0], (ts // 2, ts // 2))
             self.up_block2 = UpBlock(b[1], b[0])
             self.loftr_coarse_2c = CascadeTransformer(c["coarse3"])
-            self.cascade_matching_2c = CascadeMatching(c["match_cascade_2c"], cas(c["coarse3"]), stage="2c")
+            self.cascade_matching_2c = CascadeMatching(c["match_cascade_2c"], cas(c["coarse3"]), stage="2c", materialize_idx=False)
         self.fine_preprocess = FinePreprocess(c["coarse2"]["d_model"], c["fine"]["d_model"], c["fine_window_size"],
                                               c.get("fine_concat_coarse_feat", True))
         self.loftr_fine = FineTransformer(c["fine"])

@@ -261,7 +261,8 @@ class CasMTRIndoor4c(nn.Module):
         self.up_block1 = UpBlock(r[2], r[1])
         self.loftr_coarse_4c = IndoorCascadeTransformer(c["coarse2"])
         self.cascade_matching_4c = CascadeMatching(c["match_cascade"], {"propagation": "window", "dilated": 1,
-                                                                       "post_config": c["coarse2"]["post_config"]}, stage="4c")
+                                                                       "post_config": c["coarse2"]["post_config"]}, stage="4c",
+                                                   materialize_idx=False)
         self.cas_fine_preprocess = FinePreprocess(c["coarse2"]["d_model"], c["fine"]["d_model"], c["fine_window_size"], True)
         self.cas_loftr_fine = FineTransformer(c["fine"])
 

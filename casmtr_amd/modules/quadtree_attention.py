@@ -196,6 +196,28 @@ class QTAttB(nn.Module):
         self._last_levels = per_level if want_topk else None
         return acc
 
+    def fused_levels_with_topk(self, levels, hw_q, hw_k):
+        """Measurement / test hook: the fused path on `levels` = [(q,k,v)] of [B,C,h,w] tensors, COARSEST first, with the per-level
+        top-k tensors the reference keeps internal (:219-227) materialised -> list of per-level dicts (topk_idx, topk_score, acc, ...),
+        through whichever kernels forward() would run on these shapes."""
+        if self._quad_major_ok(hw_q, hw_k):
+            self._fused_levels_quad(levels, hw_q, hw_k, want_topk=True)
+            return self._last_levels
+        toks = ops.nchw_to_tokens_multi([t.float() for lvl in levels for t in lvl])
+        weight = self._level_weights()
+        acc = prev_idx = None
+        outs = []
+        for i in range(len(levels)):
+            q, k, v = toks[3 * i:3 * i + 3]
+            if i == 0:
+                out = ops.qta_coarse_level(q, k, v, self.nhead, self.topks[0], w_level=weight[0], want_message=False)
+            else:
+                out = ops.qta_fine_level(q, k, v, prev_idx, hw_q[i], hw_k[i], self.nhead, self.topks[i] if i < len(levels) - 1 else 0,
+                                         w_level=weight[i], acc_in=acc, want_message=False)
+            acc, prev_idx = out["acc"], out["topk_idx"]
+            outs.append(out)
+        return outs
+
     def _fused_levels(self, levels, hw_q, hw_k):
         """levels: [(q,k,v)] of token-major [B,L,C] tensors, COARSEST first; hw_q / hw_k the matching grid sizes."""
         n = len(levels)

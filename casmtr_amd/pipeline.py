@@ -293,7 +293,13 @@ class HotPath(torch.nn.Module):
 
 # ----------------------------------------------------------------------------------------------- algorithmic work
 def algorithmic_work(cfg: HotPathConfig) -> Dict[str, object]:
-    """Compulsory bytes / flops per image pair (SURVEY.md §8(d) formulas), used for roofline.achieved."""
+    """Compulsory bytes / flops per image pair, used for roofline.achieved.
+
+    `*_bytes` follow SURVEY.md section 8(d)'s formulas literally (the reference's data flow).  With implicit windows (the default
+    data flow here) two of those terms are bytes that no longer exist: the int64 `upsampled_idx` [N, 4ww] is neither written by
+    CascadeQTAttB nor read by CascadeMatching (both address their candidates from topk_pos), and the 1 -> 0 direction of
+    CascadeMatching writes no conf_matrix.  `*_bytes_moved` drop them, so a kernel's fraction of the HBM roof can be quoted against
+    the bytes it actually has to move (`frac_moved_bytes`) next to the survey's figure (`frac_survey_formula`)."""
     h8, w8 = cfg.hw8
     N0, N1, N2 = h8 * w8, (h8 // 2) * (w8 // 2), (h8 // 4) * (w8 // 4)
     C = cfg.coarse_dim
@@ -305,20 +311,31 @@ def algorithmic_work(cfg: HotPathConfig) -> Dict[str, object]:
     coarse_bytes = 8 * N0 * C + 48 * N0
     coarse_flops = 2.0 * N0 * N0 * C
     calls_q = 2 * cfg.coarse_layers
-    out = dict(qta_bytes=qta_bytes, qta_flops=qta_flops, coarse_bytes=coarse_bytes, coarse_flops=coarse_flops, stages={})
+    out = dict(qta_bytes=qta_bytes, qta_flops=qta_flops, coarse_bytes=coarse_bytes, coarse_flops=coarse_flops, stages={},
+               fine0_bytes=4 * C * (3 * N0 + N0 + N1),    # finest level: q, k, v in, message out, parent message in
+               fine1_bytes=4 * C * (3 * N1 + N1 + N2))    # middle level
     total_b, total_f = calls_q * qta_bytes + coarse_bytes, calls_q * qta_flops + coarse_flops
+    total_moved = total_b
     for st in cfg.stages:
         h, w = cfg.hw(st.div)
         N, Cf, K = h * w, st.dim, 4 * KW
-        cas_bytes = 4 * Cf * 4 * N + 8 * (N // 4) * KW * 2 + 8 * N * K + (4 * st.heads * N * K if st.rel_pos else 0)
+        rel = 4 * st.heads * N * K if st.rel_pos else 0
+        pos = 8 * (N // 4) * KW * 2
+        cas_bytes = 4 * Cf * 4 * N + pos + 8 * N * K + rel
+        cas_moved = 4 * Cf * 4 * N + pos + rel if cfg.implicit_windows else cas_bytes
         cas_flops = 2 * 2 * N * K * Cf
         match_bytes = 2 * (8 * N * Cf + 12 * N * K + 12 * N)
+        # implicit windows: per direction q + k features (8*N*Cf), topk_pos instead of the index list, next_conf + next_idx out (12*N);
+        # conf_matrix (4*N*K) in the 0 -> 1 direction only
+        match_moved = 2 * (8 * N * Cf + pos + 12 * N) + 4 * N * K if cfg.implicit_windows else match_bytes
         match_flops = 2 * 2 * N * K * Cf
-        out["stages"][st.level] = dict(cascade_bytes=cas_bytes, cascade_flops=cas_flops, match_bytes=match_bytes,
-                                       match_flops=match_flops, calls=2 * st.cross_layers)
+        out["stages"][st.level] = dict(cascade_bytes=cas_bytes, cascade_bytes_moved=cas_moved, cascade_flops=cas_flops,
+                                       match_bytes=match_bytes, match_bytes_moved=match_moved, match_flops=match_flops,
+                                       calls=2 * st.cross_layers)
         total_b += 2 * st.cross_layers * cas_bytes + match_bytes
+        total_moved += 2 * st.cross_layers * cas_moved + match_moved
         total_f += 2 * st.cross_layers * cas_flops + match_flops
     s0 = out["stages"][cfg.stages[0].level]
     out.update(cascade_bytes=s0["cascade_bytes"], cascade_flops=s0["cascade_flops"], match_bytes=s0["match_bytes"],
-               match_flops=s0["match_flops"], total_bytes=total_b, total_flops=total_f)
+               match_flops=s0["match_flops"], total_bytes=total_b, total_bytes_moved=total_moved, total_flops=total_f)
     return out

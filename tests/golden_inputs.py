@@ -247,3 +247,22 @@ def model_state(shapes):
             v = n * (1.0 / np.sqrt(fan_in))
         out[key] = np.ascontiguousarray(v, dtype=np.float32)
     return out
+
+
+# ---- GroupAttention.forward_mask padding quirk (tests/golden/gen_golden_window_attn.py, tests/test_model_harness.py)
+WINDOW_ATTN_GRIDS = [(14, 20), (20, 14), (10, 17), (14, 21)]   # ws = 7: pad (bottom, right) = (0, 1), (1, 0), (4, 4), (0, 0)
+WINDOW_ATTN_DIM, WINDOW_ATTN_HEADS, WINDOW_ATTN_WS = 64, 2, 7
+
+
+def window_attn_weights(seed=3):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    d = WINDOW_ATTN_DIM
+    return {"qkv.weight": torch.randn(3 * d, d, generator=g) / d ** 0.5, "qkv.bias": torch.randn(3 * d, generator=g),
+            "proj.weight": torch.randn(d, d, generator=g) / d ** 0.5, "proj.bias": torch.randn(d, generator=g)}
+
+
+def window_attn_tokens(H, W, seed=4):
+    import torch
+    g = torch.Generator().manual_seed(seed + 100 * H + W)
+    return torch.randn(2, H * W, WINDOW_ATTN_DIM, generator=g)

@@ -38,11 +38,19 @@ def _worker(rank, world, port, q):
     out2 = {"m_bids": torch.arange(hi - lo), "mkpts0": torch.zeros((hi - lo, 2)), "mkpts1": torch.zeros((hi - lo, 2)),
             "mconf": torch.ones(hi - lo)}
     res2 = cdist.gather_matches(out2, pair_offset=lo)
+    # --gather-every 3: two steps stay on the rank, the third triggers ONE exchange carrying all three
+    g = cdist.MatchGatherer(every=3, pair_offset=lo, pairs_per_step=5)
+    held = []
+    for stepi in range(3):
+        held.append(g.add({"m_bids": torch.arange(hi - lo), "mkpts0": torch.full((hi - lo, 2), float(stepi)),
+                           "mkpts1": torch.zeros((hi - lo, 2)), "mconf": torch.ones(hi - lo)}))
+    assert held[0] is None and held[1] is None and g.flush() is None
+    assert (held[2] is not None) == (rank == 0)
     t = cdist.max_over_ranks(float(rank))
     cdist.barrier()
     if rank == 0:
         q.put(dict(range=(lo, hi), n=res["n_total"], counts=res["counts"], bids=res["m_bids"].tolist(), shape=tuple(res["mk"].shape), tmax=t,
-                   uneven_bids=res2["m_bids"].tolist()))
+                   uneven_bids=res2["m_bids"].tolist(), every3_bids=held[2]["m_bids"].tolist(), every3_step=held[2]["mk"][:, 0].tolist()))
     else:
         assert res is None
         q.put(dict(range=(lo, hi)))
@@ -65,6 +73,9 @@ def test_world2_gloo():
     r0 = next(o for o in outs if "n" in o)
     assert r0["n"] == 4 and r0["counts"] == [4, 0] and r0["shape"] == (4, 5) and r0["bids"] == [0, 1, 0, 1] and r0["tmax"] == 1.0
     assert r0["uneven_bids"] == [0, 1, 2, 3, 4], "every pair of an uneven partition keeps its own global id"
+    # MatchGatherer(every=3): rank 0's three steps, then rank 1's; ids = step * pairs_per_step + global pair id
+    assert r0["every3_bids"] == [0, 1, 2, 5, 6, 7, 10, 11, 12, 3, 4, 8, 9, 13, 14]
+    assert r0["every3_step"] == [0., 0., 0., 1., 1., 1., 2., 2., 2., 0., 0., 1., 1., 2., 2.]
 
 
 def test_single_process_passthrough():

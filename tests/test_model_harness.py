@@ -494,3 +494,34 @@ def test_model_respects_padding_masks():
     assert float(out["mkpts0_f"][:, 0].max()) < 288
     assert float(out["stage_4c"]["mkpts1_c"][:, 1].max()) < 224
     assert float(out["mkpts1_f"][:, 1].max()) < 224 + 8
+
+
+# ---- GroupAttention.forward_mask's padding quirk: fixture from the reference module, tests/golden/gen_golden_window_attn.py
+def _window_attn_case(H, W, device):
+    import golden_inputs as gi
+    from casmtr_amd.model.casmtr4c import _WindowAttention
+    m = _WindowAttention(gi.WINDOW_ATTN_DIM, gi.WINDOW_ATTN_HEADS, gi.WINDOW_ATTN_WS, qkv_bias=True).to(device).eval()
+    m.load_state_dict(gi.window_attn_weights())
+    return m, gi.window_attn_tokens(H, W).to(device), gi.WINDOW_ATTN_GRIDS
+
+
+@pytest.mark.parametrize("hw", [(14, 20), (20, 14), (10, 17), (14, 21)], ids=lambda t: f"{t[0]}x{t[1]}")
+def test_window_attention_padding_quirk_cpu(hw):
+    """exactly one grid side a multiple of ws: the reference's mask is all ones (no masking, padded keys take part); both or neither:
+    the usual -1000 mask -- torch path of the harness against the reference module's outputs"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "window_attn_padding.npz"))
+    m, x, _ = _window_attn_case(*hw, "cpu")
+    with torch.no_grad():
+        y = m(x, *hw)
+    assert float((y - torch.from_numpy(g[f"out_{hw[0]}x{hw[1]}"])).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(14, 20), (20, 14), (10, 17), (14, 21)], ids=lambda t: f"{t[0]}x{t[1]}")
+def test_window_attention_padding_quirk_gpu(hw):
+    """the same on the GPU: the quirk sizes take the unmasked padded path, the others the HIP window kernel"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "window_attn_padding.npz"))
+    m, x, _ = _window_attn_case(*hw, "cuda:0")
+    with torch.no_grad():
+        y = m(x, *hw)
+    assert float((y.cpu() - torch.from_numpy(g[f"out_{hw[0]}x{hw[1]}"])).abs().max()) < 1e-4

@@ -1,5 +1,7 @@
 """One CascadeQTAttB workload (B=8, 208x208, H=4, K=100, smooth coarse matches) for PMC passes: `python tools/cascade_only.py [n] [debug_flags]`."""
 import os
+os.environ["CASMTR_DEBUG_HOOKS"] = "1"   # casmtr_debug_set() is ignored without this opt-in
+import os
 import sys
 
 import torch

@@ -1,6 +1,8 @@
 """Times the coarsest QTAttB level (26x26, H=8, top-32, B=8) for the fused and the three-kernel path; casmtr_debug_set bits on the
 fused kernel: 1 = stop after the logits phase, 2 = skip the row phase, 4 = stop before A.V."""
 import os
+os.environ["CASMTR_DEBUG_HOOKS"] = "1"   # casmtr_debug_set() is ignored without this opt-in
+import os
 import sys
 
 import torch

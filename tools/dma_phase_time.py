@@ -2,6 +2,8 @@
 (B=8, 208x208, C=128, K=100): casmtr_debug_set(1) removes the row transfers, (2) the arithmetic, (3) both.
 `--random` draws the coarse matches at random (windows all over the key grid) instead of a smooth shift."""
 import os
+os.environ["CASMTR_DEBUG_HOOKS"] = "1"   # casmtr_debug_set() is ignored without this opt-in
+import os
 import sys
 
 import torch

@@ -1,6 +1,8 @@
 """Times the two fine-level launches of one QTAttB call at the CasMTR-4c shapes (B=8, H=8: 52x52 with K=128 / top-16 and 104x104
 with K=64, no top-k) on random previous-level indices, for both kernels and with the phase-elimination switches."""
 import os
+os.environ["CASMTR_DEBUG_HOOKS"] = "1"   # casmtr_debug_set() is ignored without this opt-in
+import os
 import sys
 
 import torch

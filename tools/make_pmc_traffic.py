@@ -10,7 +10,11 @@ import json
 import sys
 from collections import defaultdict
 
-BENCH_NAME = [("fine_level_dma_kernel", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 64, 0>", "quad_attn_kernel<fine>"), ("quad_attn_kernel<8, 128, 0>", "quad_attn_kernel<fine>"),
+BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_kernel<2", "qta_fine_level[lists>64]"),
+              ("fine_level_dma_kernel<1", "qta_fine_level[lists<=64]"), ("fine_level_dma_kernel<2", "qta_fine_level[lists>64]"),
+              ("fine_level_vreg_kernel", "qta_fine_level[lists<=64]"),
+              ("quad_attn_kernel<8, 64, 0>", "qta_fine_level[lists<=64]"), ("quad_attn_kernel<8, 128, 0>", "qta_fine_level[lists>64]"),
+              ("nchw_to_quads_kernel", "nchw_to_quads_kernel"),
               ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
               ("coarse_fused_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
               ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
@@ -21,18 +25,21 @@ BENCH_NAME = [("fine_level_dma_kernel", "quad_attn_kernel<fine>"), ("quad_attn_k
 
 def per_kernel(path, counter):
     tot, cnt = defaultdict(float), defaultdict(int)
+    global SYMBOL
     with open(path) as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
             for pat, name in BENCH_NAME:
                 if pat in row["Kernel_Name"]:
+                    SYMBOL.setdefault(name, row["Kernel_Name"].split("(")[0])
                     tot[name] += float(row["Counter_Value"])
                     cnt[name] += 1
                     break
     return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
 
 
+SYMBOL = {}
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
@@ -40,7 +47,7 @@ for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 0))
     w, nw = write.get(k, (0.0, 0))
     out[k] = {"hbm_bytes_per_launch": round(2 * f * 1024 + w * 1024), "fetch_KB_raw": round(f, 1), "write_KB_raw": round(w, 1),
-              "launches_sampled": max(nf, nw)}
+              "launches_sampled": max(nf, nw), "symbol": SYMBOL.get(k)}
 out["_round"] = sys.argv[4] if len(sys.argv) > 4 else "unlabelled"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err                                     # headline: configs[1], 250 steps
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err                                     # headline: configs[1], 250 steps (+ other_configs legs, whole model)
 python bench.py --config 2c --steps 100 --warmup 5 > $O/${TAG}_bench_2c.json 2>> $O/${TAG}_bench.err        # configs[3]
 python bench.py --config indoor --steps 300 --warmup 10 > $O/${TAG}_bench_indoor.json 2>> $O/${TAG}_bench.err  # configs[4] shapes
 python bench.py --masked --steps 100 --warmup 5 --no-extra --no-cpu-baseline > $O/${TAG}_bench_masked.json 2>> $O/${TAG}_bench.err   # configs[2] shapes on 1 GPU

@@ -1,6 +1,8 @@
 """One implicit-window matching workload (B=8, 208x208, C=128, K=100, smooth coarse matches) for PMC passes:
 `python tools/window_only.py [n] [debug_flags]`."""
 import os
+os.environ["CASMTR_DEBUG_HOOKS"] = "1"   # casmtr_debug_set() is ignored without this opt-in
+import os
 import sys
 
 import torch
