@@ -29,7 +29,7 @@ SIGNATURES = {
     "casmtr_qta_coarse_level_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_qta_coarse_level_ws_floats": (_SZ, [_I] * 4),
     "casmtr_qta_fine_level_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
-    "casmtr_nchw_to_quads_multi": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "casmtr_nchw_to_quads_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "casmtr_tokens_to_quads": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "casmtr_topk_idx_to_tab": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "casmtr_qta_fine_level_quad_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),

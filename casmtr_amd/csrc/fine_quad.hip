@@ -28,6 +28,8 @@
 //     closer than 2^-16 relative -- redo the selection with the exact iterated argmax;
 //   V chunks (32 rows): 16 v_mfma_f32_4x4x1 each (two rows per instruction), probabilities as operand A from 4 ds_read_b128.
 // Results are in raster order of the h0 x w0 grid; final = final[parent] + message * weight (:277-281) fused into the store.
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/casmtr_hip.h"
 
@@ -47,6 +49,7 @@ struct FineQArgs {
     float temp, w_level;
     int topk, B, h0, w0, h1, w1, H, Kp, nquads, lq1;
     unsigned div_magic;      // ceil(2^32 / (w1/2)): p / (w1/2) == umulhi(p, div_magic) for p < 2^22 (0: w1/2 == 1)
+    int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores
 };
 
 // one 4 KB chunk: 4 LDS-DMA instructions, lane-linear 1 KB each.  The source offsets o1..o3 are pre-biased by -1024, -2048, -3072
@@ -107,7 +110,7 @@ __device__ __forceinline__ void merge_round(unsigned (&s)[8], bool odd) {
 }
 
 template <int NPASS, bool EXACT>   // EXACT: the level feeds a finer one (top-k requested): bit-exact sequential d-chain
-__global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(const FineQArgs a) {
+__global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(const FineQArgs a) {
     constexpr int KMAX = 64 * NPASS;
     constexpr int E = KMAX / 16;          // elements per lane in the series-per-row phase
     constexpr int KS = KMAX + 4;          // row stride of the logits transposition buffer
@@ -115,9 +118,13 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
     constexpr int P_FLOATS = 8 * PST;
     constexpr int NV = 2 * NPASS;         // V chunks per item
     static_assert(P_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
+    constexpr int WAVE_FLOATS = 2048 + P_FLOATS + 128 + 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
-    float* ring = smem;                                     // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
+    // two INDEPENDENT waves per workgroup (no block barrier anywhere): LDS is granted in coarse granules, and one wave's 9.8 KB
+    // (11 KB with lists > 64) rounded up alone leaves room for 13 single-wave workgroups per CU, two together for 16 (12) waves
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* ring = smem + wave * WAVE_FLOATS;                // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
     float* Pld = ring + 2048;                               // P[child][parity][m] (candidate 2m + parity); first the [4][KS] logits
     float* qs = Pld + P_FLOATS;                             // [4 children][32]
     int* t2 = reinterpret_cast<int*>(qs + 128);             // t2[parity * 16 + j] = parent 2j + parity
@@ -126,8 +133,8 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
     // ---- work list: XCD x -> head x % H; the 8 / H XCDs sharing a head split every pair's quads into contiguous chunks
     const int xcd = blockIdx.x & 7, h = xcd % H, G = 8 / H, g = xcd / H;
     const int chunk = (Lq + G - 1) / G, cnt = min(chunk, Lq - g * chunk);
-    const int total = cnt > 0 ? a.B * cnt : 0, stride = gridDim.x >> 3;
-    const int t = blockIdx.x >> 3;
+    const int total = cnt > 0 ? a.B * cnt : 0, stride = (gridDim.x >> 3) * 2;
+    const int t = (blockIdx.x >> 3) * 2 + wave;
     if (g >= G || t >= total) return;
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
     const int un = lane & 7;
@@ -167,6 +174,14 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
     };
     auto prefetch = [&](const Item& it) {
         const size_t qd = ((size_t)it.b * H + h) * Lq + it.quad;
+        if (a.xflags & 1) {
+            if (lane < 32) {
+                pf_p = __builtin_nontemporal_load(a.parents + qd * Kp + min(lane, Kp - 1));
+                pf_q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.q + qd * 128 + lane * 4));
+            }
+            if (a.acc_in) pf_acc = __builtin_nontemporal_load(a.acc_in + ((size_t)it.b * Lq + it.quad) * HD + h * 32 + (lane & 31));
+            return;
+        }
         if (lane < 32) {
             pf_p = a.parents[qd * Kp + min(lane, Kp - 1)];
             pf_q = *reinterpret_cast<const f32x4*>(a.q + qd * 128 + lane * 4);
@@ -193,9 +208,12 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
         }
     };
     // chunk c of pass p (rows 64p + 32c ..) of K (isv = 0) or V (isv = 1) of pair b -> ring slot c
+    const size_t pair_pitch = (size_t)H * a.lq1 * 128;                                  // floats between two pairs' slices
+    const float* const k0 = a.key + (size_t)h * a.lq1 * 128 - 768;                       // this head's slice of pair 0, 3072 bytes low
+    const float* const v0 = a.value + (size_t)h * a.lq1 * 128 - 768;
     auto issue = [&](int isv, auto pc, auto cc, int b) {
         constexpr int p = decltype(pc)::value, c = decltype(cc)::value;
-        const float* base = (isv ? a.value : a.key) + ((size_t)b * H + h) * a.lq1 * 128 - 768;   // wave-uniform; 3072 bytes low
+        const float* base = (isv ? v0 : k0) + (size_t)b * pair_pitch;   // wave-uniform
         glds_chunk(base, voff[p][4 * c + 0], voff[p][4 * c + 1], voff[p][4 * c + 2], voff[p][4 * c + 3], ring_lds + (unsigned)(c * 4096));
     };
     using I0 = std::integral_constant<int, 0>;
@@ -219,8 +237,17 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
             const size_t o = ((size_t)pend_b * L + pend_l00 + hi * a.w0) * HD + h * 32 + (lane & 31);
             if (a.message) { a.message[o] = vA; a.message[o + HD] = vB; }
             if (a.acc_out) {   // separate multiply and add (:277-281)
-                a.acc_out[o] = pend_acc + vA * a.w_level;
-                a.acc_out[o + HD] = pend_acc + vB * a.w_level;
+                const float rA = pend_acc + vA * a.w_level, rB = pend_acc + vB * a.w_level;
+                if (a.xflags & 2) {
+                    __builtin_nontemporal_store(rA, a.acc_out + o);
+                    __builtin_nontemporal_store(rB, a.acc_out + o + HD);
+                } else if (a.xflags & 4) {
+                    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(a.acc_out + o), "v"(rA) : "memory");
+                    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(a.acc_out + o + HD), "v"(rB) : "memory");
+                } else {
+                    a.acc_out[o] = rA;
+                    a.acc_out[o + HD] = rB;
+                }
             }
             if constexpr (EXACT) {
                 const int f = lane >> 4, j = lane & 15, rank = (j & 1) * 8 + (j >> 1);
@@ -306,13 +333,24 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
                 const f32x4 v = sp[e4];
                 lv[4 * e4 + 0] = v.x; lv[4 * e4 + 1] = v.y; lv[4 * e4 + 2] = v.z; lv[4 * e4 + 3] = v.w;
             }
-            unsigned lm = 0;
+            float m;
+            if constexpr (EXACT) {
+                unsigned lm = 0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                xk[e] = (j * E + e < K) ? f2ord(lv[e]) : 0u;
-                lm = max(lm, xk[e]);
+                for (int e = 0; e < E; ++e) {
+                    xk[e] = (j * E + e < K) ? f2ord(lv[e]) : 0u;
+                    lm = max(lm, xk[e]);
+                }
+                m = ord2f(row16_max_u32(lm));
+            } else {   // no selection: the maximum only centres the exponentials
+                float fm = -3.0e38f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) fm = (j * E + e < K) ? fmaxf(fm, lv[e]) : fm;
+                fm = fmaxf(fm, dpp_f32<0xB1>(fm));
+                fm = fmaxf(fm, dpp_f32<0x4E>(fm));
+                fm = fmaxf(fm, dpp_f32<0x141>(fm));
+                m = fmaxf(fm, dpp_f32<0x140>(fm));
             }
-            const float m = ord2f(row16_max_u32(lm));
             float ps[E];
             float sum = 0.f;
 #pragma unroll
@@ -320,7 +358,7 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
                 ps[e] = (j * E + e < K) ? __expf(lv[e] - m) : 0.f;
                 sum += ps[e];
             }
-            sum = 1.0f / row16_sum_f32(sum);
+            sum = __builtin_amdgcn_rcpf(row16_sum_f32(sum));   // 1 ulp: the probabilities carry a 1e-4 tolerance, no index depends on them
 #pragma unroll
             for (int e = 0; e < E; ++e) ps[e] = ps[e] * sum;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // every lane has its logits: the buffer becomes P
@@ -478,16 +516,33 @@ __global__ __launch_bounds__(64, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(con
 
 template <int NPASS, bool EXACT>
 static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
-    constexpr size_t lds = sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 128 + 32);
+    constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 128 + 32);
     // persistent grid: exactly the workgroups that are resident at once
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
-    if (const int r = resident_workgroups(resident, fine_quad_kernel<NPASS, EXACT>, 64, lds, &res)) return r;
-    const long long work = (long long)a.B * a.nquads * a.H;
-    long long blocks = res;
-    if (blocks > work) blocks = (work + 7) / 8 * 8;
+    if (const int r = resident_workgroups(resident, fine_quad_kernel<NPASS, EXACT>, 128, lds, &res)) return r;
+    // Waves per XCD.  An XCD walks the pairs one after the other, its 4 MB L2 holding one (pair, head) slice of K and V at a time.
+    // While the first waves are already on the next pair and the last ones still on this one, two slices compete for the cache; the
+    // share of the time spent like that is (waves in flight) / (items per pair).  Measured on the finest CasMTR-4c level (2.8 MB
+    // per slice, 2704 items per pair and XCD; TCC_MISS per launch / us per launch): 452 waves 6.1-9.4 M / 220, 320 waves 4.4 M / 192,
+    // 256 waves 3.5 M / 200 (3.0 M are compulsory).  So when two slices do not fit the L2 together, the wave count is capped at an
+    // eighth of a pair's items (and chosen so that every wave makes the same number of items per pair: no wave runs a round ahead).
+    // Small slices (the middle level: 0.7 MB) run at full residency.
+    const int G = 8 / a.H;                                             // XCDs sharing a head split the pair's quads
+    const long long per_pair = (a.nquads + G - 1) / G;
+    long long wpx = (long long)res / 8 * 2;                            // resident waves per XCD
+    const char* ev = getenv("CASMTR_FQ_WAVES_PER_XCD");                // measurement knob (tools/fq_sweep.py)
+    if (ev && atoi(ev) > 0) wpx = atoi(ev) < wpx ? atoi(ev) : wpx;
+    else if (2ull * 2 * a.lq1 * 512 > 3ull << 20) {                    // two K + V slices against 3 of the L2's 4 MB
+        long long rounds = (per_pair + wpx - 1) / wpx;
+        if (rounds < 8) rounds = 8;
+        wpx = (per_pair + rounds - 1) / rounds;
+    }
+    if (wpx > per_pair * a.B) wpx = per_pair * a.B;
+    const long long blocks = (wpx + 1) / 2 * 8;
+    if (getenv("CASMTR_FQ_DEBUG")) fprintf(stderr, "fine_quad<%d,%d>: %zu B LDS per workgroup, %d resident workgroups, launching %lld\n", NPASS, (int)EXACT, lds, res, blocks);
     ProfScope ps(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, s);
-    hipLaunchKernelGGL((fine_quad_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((fine_quad_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -507,6 +562,7 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
     a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.H = H; a.Kp = Kp; a.nquads = (h0 / 2) * (w0 / 2); a.lq1 = (h1 / 2) * (w1 / 2);
     const unsigned d = (unsigned)(w1 / 2);
     a.div_magic = d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u;
+    { const char* ev = getenv("CASMTR_FQ_FLAGS"); a.xflags = ev ? atoi(ev) : 0; }
     hipStream_t s = (hipStream_t)stream;
     if (topk > 0) return K <= 64 ? launch_fine_quad<1, true>(a, s) : launch_fine_quad<2, true>(a, s);
     return K <= 64 ? launch_fine_quad<1, false>(a, s) : launch_fine_quad<2, false>(a, s);

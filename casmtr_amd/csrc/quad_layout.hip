@@ -12,6 +12,7 @@ struct QuadLayoutBatch {
     const float* src[CASMTR_MAX_QLAYOUT];
     float* dst[CASMTR_MAX_QLAYOUT];
     int C[CASMTR_MAX_QLAYOUT], h[CASMTR_MAX_QLAYOUT], w[CASMTR_MAX_QLAYOUT];
+    int tokens[CASMTR_MAX_QLAYOUT];           // 1: plain token-major [B, h*w, C] (the coarsest level's operands) instead of quad-major
     int tile_begin[CASMTR_MAX_QLAYOUT + 1];   // prefix sum of tiles per tensor (per batch element)
     int n;
 };
@@ -31,6 +32,41 @@ __global__ __launch_bounds__(256) void nchw_to_quads_kernel(const QuadLayoutBatc
     const float* __restrict__ x = lb.src[ti];
     float* __restrict__ out = lb.dst[ti];
     int local = blockIdx.x - lb.tile_begin[ti];
+    if (lb.tokens[ti]) {
+        // [B,C,HW] -> [B,HW,C]: 64 channels x 64 pixels through the same LDS region (the tile of casmtr_nchw_to_tokens, qta_fused.hip)
+        float (*tt)[65] = reinterpret_cast<float (*)[65]>(t);
+        const int HW = h * w, ptiles = (HW + 63) / 64;
+        const int p0 = (local % ptiles) * 64, c0 = (local / ptiles) * 64;
+        const int b = blockIdx.y, tid = threadIdx.x;
+        const bool vin = (HW & 3) == 0;
+        {
+            const int p = p0 + (tid & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cl = (tid >> 4) + 16 * i, c = c0 + cl;
+                if (c >= C) continue;
+                const float* sp = x + ((size_t)b * C + c) * HW + p;
+                if (vin && p + 3 < HW) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+                    tt[cl][(tid & 15) * 4 + 0] = v.x; tt[cl][(tid & 15) * 4 + 1] = v.y;
+                    tt[cl][(tid & 15) * 4 + 2] = v.z; tt[cl][(tid & 15) * 4 + 3] = v.w;
+                } else {
+                    for (int u = 0; u < 4; ++u) if (p + u < HW) tt[cl][(tid & 15) * 4 + u] = sp[u];
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int cl = (tid & 15) * 4, c = c0 + cl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pl = (tid >> 4) + 16 * i, p = p0 + pl;
+                if (p >= HW || c >= C) continue;   // C % 32 == 0: a 4-channel group is in range or out of range as a whole
+                *reinterpret_cast<f32x4*>(out + ((size_t)b * HW + p) * C + c) = (f32x4){tt[cl][pl], tt[cl + 1][pl], tt[cl + 2][pl], tt[cl + 3][pl]};
+            }
+        }
+        return;
+    }
     const int xt = local % xt_n; local /= xt_n;
     const int qy = local % hq, hd = local / hq;
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -63,18 +99,19 @@ __global__ __launch_bounds__(256) void nchw_to_quads_kernel(const QuadLayoutBatc
     }
 }
 
-extern "C" int casmtr_nchw_to_quads_multi(const float* const* src, float* const* dst, const int* C, const int* h, const int* w, int n,
-                                          int B, casmtr_stream_t stream) {
+extern "C" int casmtr_nchw_to_quads_multi(const float* const* src, float* const* dst, const int* C, const int* h, const int* w,
+                                          const int* tokens, int n, int B, casmtr_stream_t stream) {
     if (n <= 0 || B <= 0) return 0;
     if (n > CASMTR_MAX_QLAYOUT) return CASMTR_ERR_UNSUPPORTED;
     QuadLayoutBatch lb{};
     lb.n = n;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
-        if ((C[i] & 31) || (h[i] & 1) || (w[i] & 1) || C[i] <= 0 || h[i] <= 0 || w[i] <= 0) return CASMTR_ERR_UNSUPPORTED;
-        lb.src[i] = src[i]; lb.dst[i] = dst[i]; lb.C[i] = C[i]; lb.h[i] = h[i]; lb.w[i] = w[i];
+        const int tok = tokens ? tokens[i] != 0 : 0;
+        if ((C[i] & 31) || C[i] <= 0 || h[i] <= 0 || w[i] <= 0 || (!tok && ((h[i] & 1) || (w[i] & 1)))) return CASMTR_ERR_UNSUPPORTED;
+        lb.src[i] = src[i]; lb.dst[i] = dst[i]; lb.C[i] = C[i]; lb.h[i] = h[i]; lb.w[i] = w[i]; lb.tokens[i] = tok;
         lb.tile_begin[i] = tiles;
-        tiles += (C[i] / 32) * (h[i] / 2) * ((w[i] / 2 + 31) / 32);
+        tiles += tok ? ((h[i] * w[i] + 63) / 64) * ((C[i] + 63) / 64) : (C[i] / 32) * (h[i] / 2) * ((w[i] / 2 + 31) / 32);
     }
     lb.tile_begin[n] = tiles;
     ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream);

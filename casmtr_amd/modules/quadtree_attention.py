@@ -172,17 +172,20 @@ class QTAttB(nn.Module):
         [B,L,topk,H] tensors (:219-227, internal to the module) are only written when asked for (want_topk: tests)."""
         n = len(levels)
         weight = self._level_weights()
-        q0, k0, v0 = ops.nchw_to_tokens_multi([t.float() for t in levels[0]])
-        fine = [t.float() for lvl in levels[1:] for t in lvl]
-        quads = []
-        nchw = [t for t in fine if not ops._is_channels_last(t)]
-        conv = iter(ops.nchw_to_quads_multi(nchw)) if nchw else iter(())
-        for t in fine:   # channels_last tensors are token-major as they stand: one token -> quad pass instead of the NCHW one
+        # ONE layout launch per call: the coarsest level's operands become token-major, every finer level's quad-major
+        flat = [t.float() for lvl in levels for t in lvl]
+        is_tok = [i < 3 for i in range(len(flat))]
+        conv_in = [(t, k) for t, k in zip(flat, is_tok) if not ops._is_channels_last(t)]
+        conv = iter(ops.nchw_to_quads_multi([t for t, _ in conv_in], [k for _, k in conv_in])) if conv_in else iter(())
+        laid = []
+        for t, k in zip(flat, is_tok):   # channels_last tensors are token-major as they stand (views); finer levels: one token -> quad pass
             if ops._is_channels_last(t):
                 B, C, h, w = t.shape
-                quads.append(ops.tokens_to_quads(t.permute(0, 2, 3, 1).reshape(B, h * w, C), h, w))
+                tok = t.permute(0, 2, 3, 1).reshape(B, h * w, C)
+                laid.append(tok if k else ops.tokens_to_quads(tok, h, w))
             else:
-                quads.append(next(conv))
+                laid.append(next(conv))
+        (q0, k0, v0), quads = laid[:3], laid[3:]
         out = ops.qta_coarse_level(q0, k0, v0, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True)
         acc, tab = out["acc"], out["topk_tab"]
         per_level = [out]

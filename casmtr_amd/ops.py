@@ -295,27 +295,31 @@ def qta_fine_level(q, key, value, prev_idx, hw0, hw1, nhead, topk, w_level=None,
     return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti)
 
 
-def nchw_to_quads_multi(xs):
+def nchw_to_quads_multi(xs, tokens=None):
     """list of [B,C_i,h_i,w_i] (same B; C_i % 32 == 0, h_i and w_i even) -> list of quad-major per-head tensors
-    [B, C_i/32, (h_i/2)*(w_i/2), 4, 32] (include/casmtr_hip.h), one launch for up to 9 tensors."""
+    [B, C_i/32, (h_i/2)*(w_i/2), 4, 32] (include/casmtr_hip.h), one launch for up to 9 tensors.
+    tokens: optional list of bools, True = convert that tensor to plain token-major [B, h_i*w_i, C_i] instead (same launch)."""
     import ctypes as C
     outs = []
+    tokens = [False] * len(xs) if tokens is None else list(tokens)
     for j in range(0, len(xs), 9):
         chunk = [x if x.is_contiguous() else x.contiguous() for x in xs[j:j + 9]]
+        tk = tokens[j:j + 9]
         for x in chunk:
             _chk(x, "x")
         B = chunk[0].shape[0]
         if any(x.shape[0] != B for x in chunk):
             raise RuntimeError("nchw_to_quads_multi: tensors must share the batch size")
-        res = [torch.empty((B, x.shape[1] // 32, (x.shape[2] // 2) * (x.shape[3] // 2), 4, 32), device=x.device, dtype=torch.float32)
-               for x in chunk]
+        res = [torch.empty((B, x.shape[2] * x.shape[3], x.shape[1]) if t else (B, x.shape[1] // 32, (x.shape[2] // 2) * (x.shape[3] // 2), 4, 32),
+                           device=x.device, dtype=torch.float32) for x, t in zip(chunk, tk)]
         n = len(chunk)
         arr = lambda vals, ty: C.cast((ty * n)(*vals), C.c_void_p)
         with torch.cuda.device(chunk[0].device):
             _lib.check(_lib.lib().casmtr_nchw_to_quads_multi(arr([x.data_ptr() for x in chunk], C.c_void_p),
                                                              arr([r.data_ptr() for r in res], C.c_void_p),
                                                              arr([x.shape[1] for x in chunk], C.c_int), arr([x.shape[2] for x in chunk], C.c_int),
-                                                             arr([x.shape[3] for x in chunk], C.c_int), n, B, _stream()),
+                                                             arr([x.shape[3] for x in chunk], C.c_int), arr([int(t) for t in tk], C.c_int),
+                                                             n, B, _stream()),
                        "nchw_to_quads_multi")
         outs += res
     return outs

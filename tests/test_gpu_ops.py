@@ -121,6 +121,11 @@ def test_quad_major_layout_passes(ops):
         assert np.array_equal(N(o), ref(x))
         B, C, h, w = x.shape
         assert np.array_equal(N(ops.tokens_to_quads(T(_tok(x)), h, w)), ref(x))
+    # one launch, mixed: token-major for some tensors (the coarsest level of a QTAttB call, odd grids allowed), quad-major for the others
+    odd = r.standard_normal((2, 96, 13, 7)).astype(np.float32)
+    mixed = ops.nchw_to_quads_multi([T(xs[0]), T(odd), T(xs[1]), T(xs[3])], tokens=[True, True, False, True])
+    assert np.array_equal(N(mixed[0]), _tok(xs[0])) and np.array_equal(N(mixed[1]), _tok(odd))
+    assert np.array_equal(N(mixed[2]), ref(xs[1])) and np.array_equal(N(mixed[3]), _tok(xs[3]))
     idx = r.integers(0, 1000, (3, 17, 5, 4)).astype(np.int64)
     assert np.array_equal(N(ops.topk_idx_to_tab(T(idx))), idx.transpose(0, 3, 1, 2).astype(np.int32))
 
