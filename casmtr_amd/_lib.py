@@ -34,6 +34,7 @@ SIGNATURES = {
     "casmtr_topk_idx_to_tab": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "casmtr_qta_fine_level_quad_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "casmtr_qta_coarse_level_tab_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "casmtr_cascade_attn_quad_fwd": (_I, [_P, _P, _P, _P, _P, _F, _P] + [_I] * 8 + [_P]),
     "casmtr_cascade_attn_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P] + [_I] * 8 + [_P]),
     "casmtr_window_warp_idx": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_dual_softmax_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _I, _P, _I, _I, _I, _I, _I, _P, _P,

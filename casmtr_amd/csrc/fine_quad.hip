@@ -30,7 +30,7 @@
 // Results are in raster order of the h0 x w0 grid; final = final[parent] + message * weight (:277-281) fused into the store.
 #include <stdio.h>
 #include <stdlib.h>
-#include "common.hpp"
+#include "quad_common.hpp"
 #include "../../include/casmtr_hip.h"
 
 using namespace casmtr;
@@ -51,26 +51,6 @@ struct FineQArgs {
     unsigned div_magic;      // ceil(2^32 / (w1/2)): p / (w1/2) == umulhi(p, div_magic) for p < 2^22 (0: w1/2 == 1)
     int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores
 };
-
-// one 4 KB chunk: 4 LDS-DMA instructions, lane-linear 1 KB each.  The source offsets o1..o3 are pre-biased by -1024, -2048, -3072
-// (the immediate offset is added to BOTH addresses) and every offset by +3072 against a base pointer that is 3072 bytes low, so
-// that they stay non-negative.  M0 is neither saved nor restored: nothing else in these kernels uses it (tools/check_fine_quad_isa.py).
-__device__ __forceinline__ void glds_chunk(const float* base_m3072, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %4\n\t"
-                 "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %3, %4 offset:3072"
-                 :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base_m3072), "s"(lds_dst) : "memory");
-}
-
-__device__ __forceinline__ unsigned row16_sum_u32(unsigned v) {
-    v += dpp_u32<0xB1>(v);
-    v += dpp_u32<0x4E>(v);
-    v += dpp_u32<0x141>(v);
-    v += dpp_u32<0x140>(v);
-    return v;
-}
 
 __device__ __forceinline__ void ce_desc(unsigned& a, unsigned& b) {   // compare-exchange: a >= b afterwards
     const unsigned hi = max(a, b), lo = min(a, b);

@@ -368,8 +368,20 @@ class CascadeQTAttB(nn.Module):
         last one is used, so callers that hold topk_pos (ops.WindowIndex) can skip the 8*N*4KW-byte write entirely."""
         if _needs_autograd(query, key, value, rel_pos):
             return self._forward_composed(query, key, value, topk_pos, rel_pos)
+        hw_q, hw_k = tuple(query.shape[2:]), tuple(key.shape[2:])
+        import os
+        if (not want_idx and os.environ.get("CASMTR_CASCADE_KERNEL", "qm") == "qm"
+                and ops.cascade_quad_supported(self.nhead, self.dim, hw_q, hw_k, topk_pos.shape[2], self.dilated)):
+            # default inference path: quad-major operands, pairs of query quads sharing one gathered window box (csrc/cascade_quad.hip)
+            ts = [t.float() for t in (query, key, value)]
+            if all(ops._is_channels_last(t) for t in ts):
+                qm = [ops.tokens_to_quads(t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, t.shape[1]), *t.shape[2:]) for t in ts]
+            else:
+                qm = ops.nchw_to_quads_multi([t.contiguous() for t in ts])
+            rp = None if rel_pos is None else rel_pos.contiguous().float()
+            return ops.cascade_attn_quad(qm[0], qm[1], qm[2], topk_pos.contiguous(), hw_q, hw_k, self.nhead, rp), None
         q, k, v = ops.nchw_to_tokens_multi([t.float() for t in (query, key, value)])
-        return self.forward_tokens(q, k, v, tuple(query.shape[2:]), tuple(key.shape[2:]), topk_pos, rel_pos, want_idx)
+        return self.forward_tokens(q, k, v, hw_q, hw_k, topk_pos, rel_pos, want_idx)
 
     def forward_tokens(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None, want_idx=True):
         """Token-major entry point: q [N,h0*w0,C], k/v [N,h1*w1,C].  Inference only."""

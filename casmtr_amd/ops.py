@@ -394,6 +394,27 @@ def cascade_attn(q, key, value, topk_pos, hw0, hw1, nhead, dilated=1, rel_pos=No
     return msg, up
 
 
+def cascade_quad_supported(nhead, head_dim, hw0, hw1, KW, dilated):
+    """shapes the quad-major cascade kernel covers (csrc/cascade_quad.hip): 5 x 5 windows, dilation 1, even grids"""
+    return (head_dim == 32 and nhead in (1, 2, 4, 8) and KW == 25 and dilated == 1 and all(v % 2 == 0 for v in (*hw0, *hw1))
+            and hw1[0] >= 10 and hw1[1] >= 10 and (hw1[0] // 2) * (hw1[1] // 2) < (1 << 22))
+
+
+def cascade_attn_quad(q, key, value, topk_pos, hw0, hw1, nhead, rel_pos=None):
+    """CascadeQTAttB on quad-major operands: q [B,H,Lq0,4,32], key/value [B,H,Lq1,4,32], topk_pos [B,Lq0,25,2] -> message [B,L,C]"""
+    _chk(q, "q"), _chk(key, "key"), _chk(value, "value"), _chk(topk_pos, "topk_pos", torch.int64), _chk(rel_pos, "rel_pos")
+    (h0, w0), (h1, w1) = hw0, hw1
+    B, H, Lq0 = q.shape[:3]
+    KW = topk_pos.shape[2]
+    if H != nhead or Lq0 * 4 != h0 * w0 or tuple(key.shape[:3]) != (B, H, (h1 // 2) * (w1 // 2)) or tuple(topk_pos.shape) != (B, Lq0, KW, 2):
+        raise RuntimeError("cascade_attn_quad: operands must be quad-major [B,H,Lq,4,32] with topk_pos [B,Lq0,KW,2]")
+    msg = torch.empty((B, h0 * w0, nhead * 32), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().casmtr_cascade_attn_quad_fwd(_ptr(q), _ptr(key), _ptr(value), _ptr(topk_pos), _ptr(rel_pos), 1.0 / 32 ** 0.5,
+                                                            _ptr(msg), B, h0, w0, h1, w1, nhead, 32, KW, _stream()), "cascade_attn_quad_fwd")
+    return msg
+
+
 def window_warp_idx(idx, H, W, ws=5):
     _chk(idx, "idx", torch.int64)
     B, N = idx.shape

@@ -128,6 +128,16 @@ int casmtr_cascade_attn_fwd(const float* q, const float* key, const float* value
                             const float* rel_pos, float temp, int dilated, float* message, int64_t* up_idx,
                             int B, int h0, int w0, int h1, int w1, int nhead, int D, int KW, casmtr_stream_t stream);
 
+/* CascadeQTAttB.forward on quad-major operands (see casmtr_nchw_to_quads_multi): q [B,H,Lq0,4,32], key/value [B,H,Lq1,4,32], topk_pos as above
+ * with KW == 25 (5 x 5 windows) and dilation 1, rel_pos nullable [B,nhead,h0*w0,100]; message [B,h0*w0,nhead*32] token-major.  Horizontally
+ * adjacent query quads whose windows are the same 5 x 5 block or one column apart share one gathered 5 x 6 box.  Window positions outside the
+ * (h1/2) x (w1/2) grid are clamped per coordinate (the reference clamps the flattened child index, :429; get_window_warp_idx never
+ * produces such positions).  Same results as casmtr_cascade_attn_fwd within the softmax tolerance; no up_idx output (callers that
+ * need the explicit list use casmtr_cascade_attn_fwd or casmtr_window_expand_idx).                                                       */
+int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, const float* value, const int64_t* topk_pos,
+                                 const float* rel_pos, float temp, float* message, int B, int h0, int w0, int h1, int w1,
+                                 int nhead, int D, int KW, casmtr_stream_t stream);
+
 /* CascadeFeatureTransformer.get_window_warp_idx, 'window' propagation (src/model/modules/transformer.py:416-440):
  *   idx [B,N] on an HxW grid -> out [B,N,ws*ws,2] (row,col) of the ws x ws window shifted inside the grid.      */
 int casmtr_window_warp_idx(const int64_t* idx, int64_t* out, int B, int N, int H, int W, int ws,

@@ -180,6 +180,64 @@ def test_cascade_attn(ops, monkeypatch, name, kernel):
     assert_close(N(msg), mo, 1e-5, "message vs oracle")
 
 
+@pytest.mark.parametrize("name", list(CASES["cascade_attn"]))
+def test_cascade_attn_quad_major_vs_reference(ops, name):
+    """the round-3 cascade kernel (quad-major operands, quad pairs sharing a window box) on the reference fixtures"""
+    inp = make_inputs("cascade_attn", name)
+    cfg = CASES["cascade_attn"][name]
+    g = load_golden("cascade_attn", name)
+    hc, wc = cfg["coarse_hw"]
+    tp = ops.window_warp_idx(T(inp["coarse_idx"]), hc, wc, cfg["ws"])
+    h, w = 2 * hc, 2 * wc
+    rel = T(inp["rel_pos"]) if cfg.get("rel_pos") else None
+    assert ops.cascade_quad_supported(cfg["nhead"], 32, (h, w), (h, w), tp.shape[2], 1)
+    qm = ops.nchw_to_quads_multi([T(inp[n]) for n in ("q", "k", "v")])
+    msg = ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, (h, w), (h, w), cfg["nhead"], rel_pos=rel)
+    assert_close(N(msg), g["message"], SOFTMAX_TOL, "message vs reference python")
+    q, k, v = (_tok(inp[n]) for n in ("q", "k", "v"))
+    mo, _ = oracle.cascade_attn(q, k, v, N(tp), (h, w), (h, w), cfg["nhead"], rel_pos=inp.get("rel_pos"))
+    assert_close(N(msg), mo, 2e-5, "message vs oracle")
+
+
+@pytest.mark.parametrize("kind", ["smooth", "random", "identical", "two_apart", "irregular", "edges"])
+@pytest.mark.parametrize("H,hc,wc,with_rel", [(4, 12, 14, False), (2, 10, 9, True), (8, 6, 7, False), (1, 8, 10, True)])
+def test_cascade_attn_quad_major_window_modes(ops, kind, H, hc, wc, with_rel):
+    """every way two horizontally adjacent quads' windows can relate: one column apart (shared 5 x 6 box), identical (5 x 5 box), two
+    columns apart / different rows / random (two single-quad sub-items), irregular position lists (not a 5 x 5 block: cells listed
+    one by one), windows pushed against the grid's edges, odd numbers of quads per row (last quad alone), every head count / XCD
+    split, several pairs, with and without rel_pos -- message against the oracle"""
+    r = np.random.default_rng(sum(map(ord, kind)) + 100 * H + hc)
+    B = 2
+    h, w, C = 2 * hc, 2 * wc, H * 32
+    q, k, v = (r.standard_normal((B, h * w, C)).astype(np.float32) for _ in range(3))
+    ys, xs = np.meshgrid(np.arange(hc), np.arange(wc), indexing="ij")
+    if kind == "smooth":
+        cy, cx = np.clip(ys + 1, 0, hc - 1), np.clip(xs + 2, 0, wc - 1)
+    elif kind == "random":
+        cy, cx = r.integers(0, hc, (hc, wc)), r.integers(0, wc, (hc, wc))
+    elif kind == "identical":
+        cy, cx = np.clip(ys, 0, hc - 1), np.clip((xs // 2) * 2 + 1, 0, wc - 1)
+    elif kind == "two_apart":
+        cy, cx = ys, np.clip(xs * 2 - wc // 2, 0, wc - 1)
+    elif kind == "edges":
+        cy, cx = np.where(ys < hc // 2, 0, hc - 1), np.where(xs < wc // 2, 0, wc - 1)
+    else:
+        cy, cx = np.clip(ys + 1, 0, hc - 1), np.clip(xs + 2, 0, wc - 1)
+    cidx = np.broadcast_to((cy * wc + cx).reshape(1, -1), (B, hc * wc)).astype(np.int64).copy()
+    tp = oracle.window_warp_idx(cidx, hc, wc, 5)
+    if kind == "irregular":   # arbitrary in-range cells for some quads: still a valid topk_pos for the op
+        sel = r.random((B, hc * wc)) < 0.3
+        tp[sel] = np.stack([r.integers(0, hc, (int(sel.sum()), 25)), r.integers(0, wc, (int(sel.sum()), 25))], -1)
+    rel = r.standard_normal((B, H, h * w, 100)).astype(np.float32) if with_rel else None
+    mo, _ = oracle.cascade_attn(q, k, v, tp, (h, w), (h, w), H, rel_pos=rel)
+    qm = [ops.tokens_to_quads(T(x), h, w) for x in (q, k, v)]
+    msg = ops.cascade_attn_quad(qm[0], qm[1], qm[2], T(tp), (h, w), (h, w), H, rel_pos=None if rel is None else T(rel))
+    assert_close(N(msg), mo, 2e-5, f"{kind}: message vs oracle")
+    if H > 1:   # (the token-major kernels cover 2, 4 and 8 heads)
+        msg_old, _ = ops.cascade_attn(T(q), T(k), T(v), T(tp), (h, w), (h, w), H, rel_pos=None if rel is None else T(rel), want_idx=False)
+        assert_close(N(msg), N(msg_old), 2e-5, f"{kind}: message vs the token-major kernel")
+
+
 def _valid_hw(m0, m1):
     return np.stack([m0.sum(1).max(-1), m0.sum(2).max(-1), m1.sum(1).max(-1), m1.sum(2).max(-1)], 1).astype(np.int32)
 

@@ -22,3 +22,25 @@ tp = ops.window_warp_idx(cidx, hc, wc, 5)
 for _ in range(n):
     ops.cascade_attn(q, k, v, tp, (h, w), (h, w), H, want_idx=False)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.cascade_attn(q, k, v, tp, (h, w), (h, w), H, want_idx=False)
+e1.record()
+torch.cuda.synchronize()
+print(f"cascade_attn (current kernel), smooth windows: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
+qm = ops.nchw_to_quads_multi([x.view(B, h, w, C).permute(0, 3, 1, 2).contiguous() for x in (q, k, v)])
+for wpx in (None, 512, 384, 256, 192, 128):
+    if wpx: os.environ["CASMTR_CQ_WAVES_PER_XCD"] = str(wpx)
+    for _ in range(3):
+        ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, (h, w), (h, w), H)
+    e0.record()
+    for _ in range(20):
+        ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, (h, w), (h, w), H)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"cascade_attn_quad (pair kernel), smooth windows, waves per XCD {wpx}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
+os.environ.pop("CASMTR_CQ_WAVES_PER_XCD", None)
+m_old, _ = ops.cascade_attn(q, k, v, tp, (h, w), (h, w), H, want_idx=False)
+m_new = ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, (h, w), (h, w), H)
+print("max abs diff old vs new:", float((m_old - m_new).abs().max()))

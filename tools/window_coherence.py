@@ -1,0 +1,27 @@
+"""How many horizontally adjacent quad pairs (2m, 2m+1) of the benchmark's cascade stage could share one 5 x 6 window box
+(same window row origin, column origins at most one cell apart)?  python tools/window_coherence.py [--config 2c] [--masked]"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from casmtr_amd import ops
+from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
+which = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "4c"
+cfg = HotPathConfig.named(which, masked="--masked" in sys.argv)
+dev = "cuda:0"
+m = HotPath(cfg).to(dev)
+inp = make_synthetic_inputs(cfg, 8, dev, seed=1234)
+with torch.no_grad():
+    m.qta.weight.copy_(inp["weight"])
+    out = m(inp)
+prev = "8c"
+for st in cfg.stages:
+    h, w = cfg.hw(st.div)
+    hp, wp = h // 2, w // 2
+    for d in ("c01", "c10"):
+        tp = ops.window_warp_idx(out["data"][f"stage_{prev}"][f"next_idx_{d}"], hp, wp, cfg.window_size)   # [B, hp*wp, 25, 2]
+        o = tp[:, :, 0, :].reshape(-1, hp, wp, 2)
+        a, b = o[:, :, 0:wp - 1:2], o[:, :, 1:wp:2]
+        share = (a[..., 0] == b[..., 0]) & ((a[..., 1] - b[..., 1]).abs() <= 1)
+        same = (a[..., 0] == b[..., 0]) & (a[..., 1] == b[..., 1])
+        print(f"{cfg.name} stage {st.level} {d}: {share.float().mean().item():.3f} of the adjacent quad pairs can share a 5x6 box "
+              f"({same.float().mean().item():.3f} have identical windows)")
+    prev = st.level
