@@ -32,6 +32,8 @@ struct CasQArgs {
     float* message;        // [B,L,H*32]
     float temp;
     int B, h0, w0, h1, w1, H, nquads, lq1, npr, nitems;   // npr = pair items per quad row, nitems = pair items per image pair
+    int colmajor;          // item order inside an XCD's chunk: 1 = down the columns of quad pairs (consecutive items of a wave's neighbours
+                           // share 4 of their 5 window rows), 0 = along the rows
 };
 
 struct Sub {   // one pipeline unit: the candidate rows of `ncells` cells against nq query quads (all wave-uniform)
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     bool regs_full = false, pendB = false;
     auto prefetch = [&](int tt) {
         const int b = tt / cnt, it = g * chunk + tt % cnt;
-        const int qy = it / a.npr, m = it % a.npr;
+        const int hq = a.nitems / a.npr;
+        const int qy = a.colmajor ? it % hq : it / a.npr, m = a.colmajor ? it / hq : it % a.npr;
         pf_b = b; pf_quadA = qy * wq + 2 * m; pf_l00A = 2 * qy * a.w0 + 4 * m; pf_hasB = 2 * m + 1 < wq;
         const int e = lane & 31, quad = pf_quadA + (lane >> 5);
         if (lane < 32 || pf_hasB) {
@@ -413,5 +416,6 @@ extern "C" int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, co
     a.q = q; a.key = key; a.value = value; a.tp = topk_pos; a.rel = rel_pos; a.message = message; a.temp = temp;
     a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.H = nhead; a.nquads = (h0 / 2) * (w0 / 2); a.lq1 = (h1 / 2) * (w1 / 2);
     a.npr = (w0 / 2 + 1) / 2; a.nitems = (h0 / 2) * a.npr;
+    { const char* ev = getenv("CASMTR_CQ_ORDER"); a.colmajor = !(ev && ev[0] == 'r'); }
     return rel_pos ? launch_cas_quad<true>(a, (hipStream_t)stream) : launch_cas_quad<false>(a, (hipStream_t)stream);
 }

@@ -71,7 +71,19 @@ __global__ __launch_bounds__(256) void nchw_to_quads_kernel(const QuadLayoutBatc
     const int qy = local % hq, hd = local / hq;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int q0 = xt * 32;   // first quad of the tile in its row
-    {   // read: thread -> (channel tid/64 + 4 i, image row (tid/32)%2, pixel pair tid%32)
+    if ((w & 3) == 0) {   // read: thread -> (channel tid/32 + 8 i, image row (tid/16)%2, 4 pixels tid%16): 16-byte accesses
+        const int x4 = tid & 15, r = (tid >> 4) & 1;
+        const int px = 2 * q0 + 4 * x4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = (tid >> 5) + 8 * i;
+            if (px < w) {   // w % 4 == 0: the 4 pixels are in range or out of range together
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * C + hd * 32 + ch) * h + 2 * qy + r) * w + px);
+                float* tp = t + r * RS + ch * 65 + 4 * x4;
+                tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
+            }
+        }
+    } else {              // thread -> (channel tid/64 + 4 i, image row (tid/32)%2, pixel pair tid%32): 8-byte accesses (w even)
         const int x2 = tid & 31, r = (tid >> 5) & 1;
         const int px = 2 * (q0 + x2);
 #pragma unroll

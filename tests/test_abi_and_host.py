@@ -166,3 +166,13 @@ def test_fine_vreg_isa_guard():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_vreg_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_quad_kernels_isa_guard():
+    """fine_quad.hip / cascade_quad.hip issue their LDS-DMA chunks from inline asm that writes M0 and is waited for with hand-counted
+    vmcnt: the compiled kernels must not touch M0 elsewhere and must not spill (tools/check_quad_isa.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_quad_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Build-time guard for the quad-major LDS-DMA kernels (casmtr_amd/csrc/fine_quad.hip, cascade_quad.hip).  Their DMA chunks are
+issued from inline asm that (a) writes M0 without saving it and (b) is waited for with hand-counted `s_waitcnt vmcnt(N)`.  Both are
+only sound if the compiler
+  * never touches M0 itself in these kernels (every M0 reference must sit inside an ;;#ASMSTART / ;;#ASMEND block), and
+  * never spills (a scratch load / store between a DMA issue and its wait changes the vector-memory count the waits rely on).
+Compiles both files to gfx950 assembly and checks every template instance.  Exit status 0 = ok."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = {"fine_quad.hip": ("fine_quad_kernel", 4), "cascade_quad.hip": ("cascade_quad_kernel", 2)}
+
+
+def check(asm_text, kernel, n_expected):
+    problems = []
+    names = sorted(set(re.findall(rf"^(_Z\d+{kernel}\w+):", asm_text, re.M)))
+    if len(names) != n_expected:
+        return [f"{kernel}: expected {n_expected} instances, found {names}"]
+    for name in names:
+        body = asm_text.split(name + ":", 1)[1].split(".Lfunc_end", 1)[0]
+        lines = body.split("\n")
+        if any(re.match(r"\s*scratch_", l) for l in lines):
+            problems.append(f"{name}: scratch instructions present (register spills)")
+        in_asm = False
+        ndma = 0
+        for l in lines:
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            code = l.split(";")[0]
+            if re.search(r"\bm0\b", code) and not in_asm:
+                problems.append(f"{name}: compiler-generated M0 access: {code.strip()}")
+            if "global_load_lds_dwordx4" in code:
+                ndma += 1
+                if not in_asm:
+                    problems.append(f"{name}: LDS-DMA outside inline asm")
+        if ndma == 0:
+            problems.append(f"{name}: no LDS-DMA instructions found")
+        meta = asm_text.split(f".name:           {name}", 1)
+        if len(meta) == 2:
+            m = re.search(r"\.vgpr_spill_count:\s*(\d+)", meta[1])
+            p = re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta[1])
+            if m and int(m.group(1)) != 0:
+                problems.append(f"{name}: vgpr_spill_count {m.group(1)}")
+            if p and int(p.group(1)) != 0:
+                problems.append(f"{name}: private segment {p.group(1)} bytes")
+    return problems
+
+
+def main():
+    bad = []
+    with tempfile.TemporaryDirectory() as td:
+        for f, (kernel, n) in FILES.items():
+            src = os.path.join(ROOT, "casmtr_amd", "csrc", f)
+            out = os.path.join(td, f + ".s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
+                                   "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+            bad += check(open(out).read(), kernel, n)
+    for b in bad:
+        print("FAIL:", b)
+    print("ok" if not bad else f"{len(bad)} problem(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -16,6 +16,7 @@ BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_k
               ("quad_attn_kernel<8, 64, 0>", "qta_fine_level[lists<=64]"), ("quad_attn_kernel<8, 128, 0>", "qta_fine_level[lists>64]"),
               ("nchw_to_quads_kernel", "nchw_to_quads_kernel"),
               ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
+              ("cascade_quad_kernel", "quad_attn_kernel<cascade>"),
               ("coarse_fused_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
               ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
               ("nchw_to_tokens_kernel", "nchw_to_tokens_kernel"), ("coarse_row_kernel", "coarse_row_kernel"),
