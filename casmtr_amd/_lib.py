@@ -40,6 +40,9 @@ SIGNATURES = {
     "casmtr_dual_softmax_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _I, _P, _I, _I, _I, _I, _I, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "casmtr_dual_softmax_ws_bytes": (_SZ, [_I] * 3),
+    "casmtr_dual_softmax_split_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _I, _P, _I, _I, _I, _I, _I, _P, _P,
+                                           _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "casmtr_dual_softmax_split_ws_bytes": (_SZ, [_I] * 4),
     "casmtr_window_match_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P] + [_I] * 7 + [_P]),
     "casmtr_window_match_pos_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P] + [_I] * 7 + [_P]),
     "casmtr_window_expand_idx": (_I, [_P, _P] + [_I] * 7 + [_P]),
@@ -58,7 +61,7 @@ SIGNATURES = {
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
 }
-PROF_COUNT = 18
+PROF_COUNT = 20
 
 
 def prof_enable(on: bool):

@@ -1,0 +1,259 @@
+// Dual-softmax similarity matrix on the f16 matrix pipe of gfx950, fp32-accurate, with exact index decisions.
+//   CoarseMatching.forward: sim = einsum(feat_c0 / sqrt(C), feat_c1 / sqrt(C)) / T      src/model/functions/coarse_matching.py:59-63
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 vector rate, 1/16 of the f16 / bf16 MFMA rate, and the exact kernel in
+// matching.hip already saturates it.  Here each operand row is normalised by a power of two so that its largest element lies
+// in [512, 1024) and split into two f16 terms, a = hi + lo + r, |r| <= 2^-22 |a| (lo is a normal f16 for every element within
+// 2^-13 of the row maximum; smaller elements round at 2^-25 absolute = 2^-34 of the row maximum).  v_mfma_f32_32x32x16_f16
+// multiplies f16 exactly and accumulates in fp32:
+//      a.b  ~  lo_a.hi_b + hi_a.lo_b + hi_a.hi_b          (dropped: lo.lo and the r terms, <= 3 x 2^-22 sum|a b|)
+// i.e. 3/16 of the fp32 MFMA time.  Error budget against the oracle's chain (fmaf over c ascending of the 1/sqrt(C)-scaled
+// operands, then / T), all relative to sum_c |a_c b_c| / (C T) <= |a_i| |b_j| / (C T):
+//      the chain itself  (C + 3) 2^-24  (worst case, C = 256: 1.55e-5)      split 3 x 2^-22 = 7.2e-7
+//      48 fp32 MFMA accumulations + 2 scalings  <= 50 x 2^-23 = 6.0e-6      => e_ij = 2^-15 |a_i| |b_j| / (C T)  (3.05e-5)
+// An entry can be its row's exact maximum only if its approximate logit is >= max~ - 2 e_i (e_i with max_j |b_j|): those are
+// the row's candidates (ds_conf_kernel<true> collects them while it streams the matrix anyway); a row with one candidate has
+// its argmax, a row with several re-evaluates them with the exact chain here (ds_fix_kernel) -- about 0.4 % of the rows on
+// random features.  Sums, probabilities and confidences use the approximate logits (relative error of exp < 1e-4 x |a||b|/(C T) x 0.3).
+#include <stdlib.h>
+#include <math.h>
+#include "ds_common.hpp"
+#include "../../include/casmtr_hip.h"
+
+namespace casmtr {
+
+// =================================================================================================== operand images
+// One workgroup per 128-row block.  Phase 1 (wave per row, coalesced 1 KB reads): row maximum -> exponent, row norm.
+// Phase 2 (lane <-> row, 32 B of a row per lane and step, L2-warm): normalise, split, write the tile image
+//   img[b][rb][ks = c/32][kg = (c/8)%4][part hi/lo][row 128][8 f16]   -- 16 KB per (row block, k-stage), every 1 KB of it one
+// wave-instruction of the GEMM's LDS-DMA and, inside a kg plane, the lane-linear 16-B runs its ds_read_b128 fragment loads want.
+__global__ __launch_bounds__(256) void ds_split_kernel(const float* __restrict__ f, int N, int C, float inv_sqrtC,
+                                                       float k0, _Float16* __restrict__ img, float* __restrict__ fac,
+                                                       float* __restrict__ nrm, unsigned* __restrict__ nmax, int NRB) {
+    __shared__ int ex[128];
+    const int rb = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Np = NRB * 128;
+    float wmax = 0.f;
+    for (int rr = 0; rr < 32; ++rr) {
+        const int r = wave * 32 + rr, gi = rb * 128 + r;
+        float mx = 0.f, ss = 0.f;
+        if (gi < N) {
+            const float* p = f + ((size_t)b * N + gi) * C;
+            for (int c = lane * 4; c < C; c += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        }
+        mx = wave_max_f32(mx);
+        ss = wave_sum_f32(ss);
+        // largest element -> [512, 1024): products < 2^20, 256-term sums < 2^28, f16 hi parts far from 65504
+        const int e = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
+        // |a| / sqrt(C), rounded up: 1.001 covers the fp32 summation (<= C 2^-24 relative) and the square root
+        const float nr = sqrtf(ss) * inv_sqrtC * 1.001f;
+        if (lane == 0) {
+            ex[r] = e;
+            fac[(size_t)b * Np + gi] = gi < N ? ldexpf(k0, e) : 0.f;
+            nrm[(size_t)b * Np + gi] = gi < N ? nr : 0.f;
+        }
+        if (gi < N) wmax = fmaxf(wmax, nr);
+    }
+    if (lane == 0 && wmax > 0.f) atomicMax(nmax + b, __float_as_uint(wmax));
+    __syncthreads();
+    const int r = tid & 127, gi = rb * 128 + r, e = ex[r];
+    const float* p = f + ((size_t)b * N + (gi < N ? gi : N - 1)) * C;
+    char* out = reinterpret_cast<char*>(img) + ((size_t)b * NRB + rb) * (size_t)(C / 32) * 16384 + r * 16;
+    for (int g = tid >> 7; g < C / 8; g += 2) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(p + 8 * g), v1 = *reinterpret_cast<const f32x4*>(p + 8 * g + 4);
+        if (gi >= N) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        h16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xn = ldexpf(x[c], -e);
+            const _Float16 h = (_Float16)xn;
+            hi[c] = h;
+            lo[c] = (_Float16)(xn - (float)h);
+        }
+        char* o = out + (size_t)(g >> 2) * 16384 + (g & 3) * 4096;
+        *reinterpret_cast<h16x8*>(o) = hi;
+        *reinterpret_cast<h16x8*>(o + 2048) = lo;
+    }
+}
+
+int ds_split_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
+                    hipStream_t s) {
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    const float sqrtC = (float)sqrt((double)C);
+    const float k0 = (float)(1.0 / ((double)C * (double)temperature));
+    (void)recip;   // the operand pre-scaling mode only matters to the exact chain (ds_fix_kernel)
+    hipLaunchKernelGGL(ds_split_kernel, dim3(NIB, B), dim3(256), 0, s, feat0, L, C, 1.0f / sqrtC, k0, w.imgA, w.fa, w.na, w.namax, NIB);
+    hipLaunchKernelGGL(ds_split_kernel, dim3(NJB, B), dim3(256), 0, s, feat1, S, C, 1.0f / sqrtC, 1.0f, w.imgB, w.fb, w.nb, w.nbmax, NJB);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================== GEMM
+// 4 KB = 4 lane-linear LDS-DMA instructions behind one M0 write: the immediate offset advances the LDS destination and the
+// source address together (tools/probes/glds_offset.hip).  M0 is not restored: nothing else in this kernel uses it.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {   // pins a wave-uniform address to an SGPR pair
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds_4k(const char* base, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:3072"
+                 :: "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// 128 x 128 block tile, 4 waves x (64 x 64), k-stages of 32 (16 KB of A image + 16 KB of B image), double buffered: the DMA
+// of stage ks+1 is in flight while stage ks feeds 24 MFMAs per wave.  2 workgroups per CU (2 x 65 KB LDS): one workgroup's
+// epilogue (VALU / LDS / stores) overlaps the other's MFMA loop.
+#define DS16_STAGE 32768
+__global__ __launch_bounds__(256, 2) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
+                                                           const float* __restrict__ fa, const float* __restrict__ fb,
+                                                           const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B), then facA[128] | facB[128]
+    char* lds = reinterpret_cast<char*>(smem);
+    float* facA = smem + 2 * DS16_STAGE / 4;
+    float* facB = facA + 128;
+    const int NSJ = (NJB + 7) >> 3;
+    const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
+    const int st = t >> 6, wi = t & 63;
+    const int tI = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
+    if (tI >= NIB || tJ >= NJB) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    if (tid < 128) facA[tid] = fa[((size_t)b * NIB + tI) * 128 + tid];
+    else facB[tid - 128] = fb[((size_t)b * NJB + tJ) * 128 + tid - 128];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const char* a_src = uniform_ptr(reinterpret_cast<const char*>(imgA) + ((size_t)b * NIB + tI) * (size_t)KS * 16384);
+    const char* b_src = uniform_ptr(reinterpret_cast<const char*>(imgB) + ((size_t)b * NJB + tJ) * (size_t)KS * 16384);
+    const unsigned voff = (unsigned)(wave * 4096 + lane * 16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_byte_addr(lds) + (unsigned)(wave * 4096)));
+    __syncthreads();   // the factor loads above have completed (compiler-counted) before any DMA is outstanding
+    glds_4k(a_src, voff, lds0);
+    glds_4k(b_src, voff, lds0 + 16384);
+    const int hi = lane >> 5, ln = lane & 31;
+    // fragment (ti, part) of sub-step `sub`: plane (kg = 2 sub + hi, part), row wr*64 + ti*32 + ln
+    const char* fa_base = lds + (hi * 2) * 2048 + (wr * 64 + ln) * 16;
+    const char* fb_base = lds + 16384 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
+    for (int ks = 0; ks < KS; ++ks) {
+        glds_wait<0>();
+        __syncthreads();   // stage ks has landed for every wave; everyone is done reading the other buffer
+        const int buf = ks & 1;
+        if (ks + 1 < KS) {
+            glds_4k(a_src + (size_t)(ks + 1) * 16384, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE));
+            glds_4k(b_src + (size_t)(ks + 1) * 16384, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE) + 16384);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            h16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const char* pa = fa_base + buf * DS16_STAGE + sub * 8192 + ti * 512;
+                const char* pb = fb_base + buf * DS16_STAGE + sub * 8192 + ti * 512;
+                ah[ti] = *reinterpret_cast<const h16x8*>(pa);
+                al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
+                bh[ti] = *reinterpret_cast<const h16x8*>(pb);
+                bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
+            }
+            // small terms first; every accumulator is touched again only after three other MFMAs
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
+    ds_tile_epilogue<true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
+}
+
+int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s) {
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    const size_t lds = 2 * DS16_STAGE + 2 * 128 * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
+    hipLaunchKernelGGL(ds_gemm16_kernel, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
+                       C / 32, NJB, NIB);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================== exact re-decision
+// Thread per row (t < B*L) / per column: 0 candidates = fully masked -> index 0 (the first of the equal maxima); 1 -> that one;
+// more -> the oracle's logit for each (fmaf chain over c ascending of the 1/sqrt(C)-scaled operands, then / T -- what
+// v_mfma_f32_32x32x2_f32 computes in the exact kernel) and the first maximum.  Candidates are never masked entries.
+template <bool RECIP>
+__global__ __launch_bounds__(256) void ds_fix_kernel(const float* __restrict__ f0, const float* __restrict__ f1, DsWs w, int B, int L,
+                                                     int S, int C, float sqrtC, float inv_sqrtC, float T, float invT,
+                                                     int64_t* __restrict__ next_idx01, int64_t* __restrict__ next_idx10) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * (L + S)) return;
+    const bool col = t >= B * L;
+    const int u = col ? t - B * L : t;
+    const int N = col ? S : L;
+    const int b = u / N, self = u % N;
+    const int n = min((col ? w.ccnt : w.rcnt)[u], DS_CAND_CAP);
+    const int* cand = (col ? w.ccand : w.rcand) + (size_t)u * DS_CAND_CAP;
+    int best = 0;
+    if (n == 1) best = cand[0];
+    else if (n > 1) {
+        float bx = -INFINITY;
+        best = cand[0];
+        for (int k = 0; k < n; ++k) {
+            const int other = cand[k];
+            const int i = col ? other : self, j = col ? self : other;
+            const float* pa = f0 + ((size_t)b * L + i) * C;
+            const float* pb = f1 + ((size_t)b * S + j) * C;
+            float acc = 0.f;
+            for (int c = 0; c < C; c += 4) {
+                const f32x4 va = *reinterpret_cast<const f32x4*>(pa + c), vb = *reinterpret_cast<const f32x4*>(pb + c);
+                acc = __builtin_fmaf(div_scalar<RECIP>(va.x, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.x, sqrtC, inv_sqrtC), acc);
+                acc = __builtin_fmaf(div_scalar<RECIP>(va.y, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.y, sqrtC, inv_sqrtC), acc);
+                acc = __builtin_fmaf(div_scalar<RECIP>(va.z, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.z, sqrtC, inv_sqrtC), acc);
+                acc = __builtin_fmaf(div_scalar<RECIP>(va.w, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.w, sqrtC, inv_sqrtC), acc);
+            }
+            const float x = div_scalar<RECIP>(acc, T, invT);
+            if (x > bx || (x == bx && other < best)) { bx = x; best = other; }
+        }
+    }
+    (col ? next_idx10 : next_idx01)[u] = best;
+}
+
+int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
+                  int64_t* next_idx01, int64_t* next_idx10, hipStream_t s) {
+    const float sqrtC = (float)sqrt((double)C);
+    const int total = B * (L + S);
+    if (recip)
+        hipLaunchKernelGGL(ds_fix_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, s, feat0, feat1, w, B, L, S, C, sqrtC,
+                           1.0f / sqrtC, temperature, 1.0f / temperature, next_idx01, next_idx10);
+    else
+        hipLaunchKernelGGL(ds_fix_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, s, feat0, feat1, w, B, L, S, C, sqrtC,
+                           1.0f / sqrtC, temperature, 1.0f / temperature, next_idx01, next_idx10);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace casmtr

@@ -9,6 +9,7 @@
 // result scaled by 1/T, masked entries = -1e9, argmax = first maximum of the LOGITS.
 #include <stdlib.h>
 #include "common.hpp"
+#include "ds_common.hpp"
 #include "../../include/casmtr_hip.h"
 
 using namespace casmtr;
@@ -18,50 +19,16 @@ using namespace casmtr;
 // BK = 32.  The epilogue parks the tile in LDS, derives per-row / per-column (max, first argmax, sum exp) partials
 // for this block, and streams the tile to HBM (it is re-read once by pass 2; 468 MB/pair at 832x832 is cheaper
 // to move at 8 TB/s than to recompute at 157 TFLOP/s).
-#define DS_BM 128
-#define DS_BN 128
-#define DS_BK 32
-
-struct DsWs {  // carve of stats_ws
-    float *rp_m, *rp_s; int* rp_a;   // row partials  [B][NJB][L]
-    float *cp_m, *cp_s; int* cp_a;   // col partials  [B][NIB][S]
-    float *rmax, *rsum, *cmax, *csum;  // [B*L], [B*S]
-    unsigned long long *rbest, *cbest;  // packed (conf bits << 32 | ~idx)
-    unsigned char* flags;            // [B*L]
-    int64_t* jsel;                   // [B*L]
-    float* csel;                     // [B*L]
-    int* blk;                        // compaction block counts
-};
-
-static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-
-static size_t ds_carve(DsWs* w, char* base, int B, int L, int S) {
-    const size_t NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
-    size_t off = 0;
-#define CARVE(field, type, count)                                   \
-    do {                                                            \
-        if (w) w->field = reinterpret_cast<type*>(base + off);      \
-        off += align256(sizeof(type) * (size_t)(count));            \
-    } while (0)
-    CARVE(rp_m, float, (size_t)B * NJB * L); CARVE(rp_s, float, (size_t)B * NJB * L); CARVE(rp_a, int, (size_t)B * NJB * L);
-    CARVE(cp_m, float, (size_t)B * NIB * S); CARVE(cp_s, float, (size_t)B * NIB * S); CARVE(cp_a, int, (size_t)B * NIB * S);
-    CARVE(rmax, float, (size_t)B * L); CARVE(rsum, float, (size_t)B * L);
-    CARVE(cmax, float, (size_t)B * S); CARVE(csum, float, (size_t)B * S);
-    CARVE(rbest, unsigned long long, (size_t)B * L); CARVE(cbest, unsigned long long, (size_t)B * S);
-    CARVE(flags, unsigned char, (size_t)B * L); CARVE(jsel, int64_t, (size_t)B * L); CARVE(csel, float, (size_t)B * L);
-    CARVE(blk, int, ((size_t)B * L + 1023) / 1024 + 8);
-#undef CARVE
-    return off;
-}
-
-extern "C" size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S) { return ds_carve(nullptr, nullptr, B, L, S); }
+extern "C" size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S) { return ds_carve(nullptr, nullptr, B, L, S, 0); }
+extern "C" size_t casmtr_dual_softmax_split_ws_bytes(int B, int L, int S, int C) { return ds_carve(nullptr, nullptr, B, L, S, C); }
 
 template <bool RECIP>
 __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                          const uint8_t* __restrict__ mask0,
                                                          const uint8_t* __restrict__ mask1, float* __restrict__ sim,
                                                          DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
-                                                         float T, float invT, int NJB, int NIB) {
+                                                         float T, float invT, int NJB, int NIB, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;   // fallback launch of the split path: runs only when its candidate lists overflowed
     extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33], then epilogue scratch
     float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
     float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
@@ -119,127 +86,20 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
-    // ------------------------------------------------------------------------------------------------ epilogue
-    // Works from the accumulator registers (a version that parked the tile in LDS and looped over it cost as much as
-    // the whole MFMA loop at one workgroup per CU):
-    //   1. scale by 1/T, apply the padding mask, store the tile straight from registers (128-B coalesced half-waves);
-    //   2. column (max, first argmax, sum exp) over the wave's 64 rows: in-lane scan + one xor-32 exchange;
-    //   3. row statistics over the wave's 64 columns: 32-row slabs through a wave-private LDS region, lane <-> row;
-    //   4. the two waves sharing rows / columns combine through a small LDS exchange -> one partial per 128-wide block.
-    __syncthreads();  // every wave is done reading As/Bs: the region becomes scratch
-    float* wl = smem + wave * (32 * 65);            // wave-private [32][65]
-    float* rowx = smem + 4 * 32 * 65;               // [2 wc][128 rows][3]
-    float* colx = rowx + 2 * 128 * 3;               // [2 wr][128 cols][3]
-    const int hi = lane >> 5, ln = lane & 31;
-    bool colok[2];
-    unsigned char m1v[2] = {1, 1};
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int gj = j0 + wc * 64 + tj * 32 + ln;
-        colok[tj] = gj < S;
-        if (mask0 && colok[tj]) m1v[tj] = mask1[(size_t)b * S + gj];
-    }
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gi = i0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool rowok = gi < L;
-            const bool m0v = (mask0 && rowok) ? mask0[(size_t)b * L + gi] != 0 : true;
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
-                float x = div_scalar<RECIP>(acc[ti][tj][r], T, invT);
-                if (mask0 && !(m0v && m1v[tj])) x = NEG_FILL;
-                const bool ok = rowok && colok[tj];
-                if (ok) sim[((size_t)b * L + gi) * S + j0 + wc * 64 + tj * 32 + ln] = x;
-                acc[ti][tj][r] = ok ? x : -INFINITY;  // out-of-range entries never win a max and add exp(-inf) = 0
-            }
-        }
-    // ---- 2. columns
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        float m = -INFINITY; int am = 0;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {  // (ti, r>>2, r&3) ascending == row ascending for this half-wave
-                const float x = acc[ti][tj][r];
-                if (x > m) { m = x; am = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
-            }
-        const float pm = __shfl_xor(m, 32);
-        const int pa = __shfl_xor(am, 32);
-        if (pm > m || (pm == m && pa < am)) { m = pm; am = pa; }
-        float sm = 0.f;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sm += __expf(acc[ti][tj][r] - m);
-        sm += __shfl_xor(sm, 32);
-        if (hi == 0) {
-            float* o = colx + (wr * 128 + wc * 64 + tj * 32 + ln) * 3;
-            o[0] = m; o[1] = sm; o[2] = __int_as_float(wr * 64 + am);
-        }
-    }
-    // ---- 3. rows
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) wl[((r & 3) + 8 * (r >> 2) + 4 * hi) * 65 + tj * 32 + ln] = acc[ti][tj][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float* rp = wl + ln * 65 + hi * 32;   // lane <-> (row ln, column half hi)
-        float v[32];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) v[c] = rp[c];
-        float m = -INFINITY; int am = 0;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) if (v[c] > m) { m = v[c]; am = hi * 32 + c; }
-        const float pm = __shfl_xor(m, 32);
-        const int pa = __shfl_xor(am, 32);
-        if (pm > m || (pm == m && pa < am)) { m = pm; am = pa; }
-        float sm = 0.f;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) sm += __expf(v[c] - m);
-        sm += __shfl_xor(sm, 32);
-        if (hi == 0) {
-            float* o = rowx + (wc * 128 + wr * 64 + ti * 32 + ln) * 3;
-            o[0] = m; o[1] = sm; o[2] = __int_as_float(wc * 64 + am);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
-    // ---- 4. combine the two waves that share a row (wc = 0,1) / a column (wr = 0,1); the lower block wins ties
-    {
-        const float* x0 = (tid < 128 ? rowx : colx) + (tid & 127) * 3;
-        const float* x1 = x0 + 128 * 3;
-        const float ma = x0[0], mb = x1[0];
-        const float mm = mb > ma ? mb : ma;
-        const int aa = __float_as_int(mb > ma ? x1[2] : x0[2]);
-        float tot = 0.f;
-        if (ma > -INFINITY) tot += x0[1] * __expf(ma - mm);
-        if (mb > -INFINITY) tot += x1[1] * __expf(mb - mm);
-        if (tid < 128) {
-            if (i0 + tid < L) {
-                const size_t o = ((size_t)b * NJB + tJ) * L + i0 + tid;
-                w.rp_m[o] = mm; w.rp_s[o] = tot; w.rp_a[o] = j0 + aa;
-            }
-        } else if (j0 + tid - 128 < S) {
-            const size_t o = ((size_t)b * NIB + tI) * S + j0 + tid - 128;
-            w.cp_m[o] = mm; w.cp_s[o] = tot; w.cp_a[o] = i0 + aa;
-        }
-    }
+    __syncthreads();  // every wave is done reading As/Bs: the region becomes the epilogue's scratch
+    ds_tile_epilogue<RECIP, false>(acc, smem, nullptr, nullptr, mask0, mask1, sim, w, b, tI, tJ, L, S, T, invT, NJB, NIB);
 }
 
 // combine block partials -> per row/col (max, sum, first argmax); next_conf = softmax value at the argmax = 1/sum.
+// Split path (pa == nullptr): no argmax here; instead the near-tie threshold of the row / column: every entry whose exact logit
+// can equal the exact maximum has an approximate logit >= max~ - 2 e, e = 2^-15 |a_i| max_j |b_j| / (C T) (ds_split.hip).
 __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
                                                         const int* __restrict__ pa, int nblk, int N, int total,
                                                         float* __restrict__ omax, float* __restrict__ osum,
-                                                        int64_t* __restrict__ oidx, float* __restrict__ oconf) {
+                                                        int64_t* __restrict__ oidx, float* __restrict__ oconf,
+                                                        const float* __restrict__ nrm, int npad, const unsigned* __restrict__ other_max,
+                                                        float kthr, float* __restrict__ othr, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int b = t / N, i = t % N;
@@ -251,11 +111,16 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
         const float x = pm[base + (size_t)k * N];
         if (x > m) { m = x; kb = k; }   // strict: the first block holding the maximum wins
     }
-    const int am = pa[base + (size_t)kb * N];
     float s = 0.f;
 #pragma unroll 8
     for (int k = 0; k < nblk; ++k) s += ps[base + (size_t)k * N] * __expf(pm[base + (size_t)k * N] - m);
-    omax[t] = m; osum[t] = s; oidx[t] = am; oconf[t] = 1.0f / s;
+    omax[t] = m; osum[t] = s; oconf[t] = 1.0f / s;
+    if (pa) oidx[t] = pa[base + (size_t)kb * N];
+    else {
+        // fully masked row (all NEG_FILL): no candidates, the fix-up pass answers 0 = the first maximum
+        const float e2 = kthr * nrm[(size_t)b * npad + i] * __uint_as_float(other_max[b]);
+        othr[t] = (m == NEG_FILL) ? INFINITY : m - e2 - fabsf(m) * 9.5367431640625e-7f;
+    }
 }
 
 // Pass 2: conf = softmax10 * softmax01 (coarse_matching.py:66-68), best-of-row / best-of-column (value, first index)
@@ -268,7 +133,12 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
 // a row / column maximum that takes part in a match is attained by such an entry): conf = p01 * p10 > thr needs p01 > thr,
 // i.e. sim > rmax + log(thr * rsum).  A (row, wave) pair none of whose 256 entries passes that test (minus a slack far above
 // the rounding of __expf) is skipped after 4 compares and a ballot -- almost all of them: the pass becomes a pure read.
-__global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf, float thr) {
+// CAND (split path): entries at or above the near-tie threshold of their row / column are appended to that row's / column's
+// candidate list (almost always exactly one: the maximum itself).  Masked entries never are.
+template <bool CAND>
+__global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf, float thr,
+                                                      const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
     const int b = blockIdx.z, i0 = blockIdx.y * DSC_ROWS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -276,17 +146,19 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
     if (blockIdx.x * 1024 + wave * 256 >= S) return;
     const bool vec = (S & 3) == 0 && j + 3 < S;
     const int nr = min(DSC_ROWS, L - i0);
-    float cm[4], cinv[4], best[4];
+    float cm[4], cinv[4], best[4], cth[4];
     int bi[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int jj = min(j + u, S - 1);
+        cth[u] = CAND ? w.cthr[(size_t)b * S + jj] : 0.f;
         cm[u] = w.cmax[(size_t)b * S + jj];
         cinv[u] = 1.0f / w.csum[(size_t)b * S + jj];
         best[u] = -1.f; bi[u] = 0;
     }
     const float* rmax = w.rmax + (size_t)b * L + i0;   // wave-uniform
     const float* rsum = w.rsum + (size_t)b * L + i0;
+    const float* rthr = CAND ? w.rthr + (size_t)b * L + i0 : nullptr;
     float* base = sim + ((size_t)b * L + i0) * S + j;
     constexpr int RU = 4;  // rows in flight per lane
     for (int r0 = 0; r0 < nr; r0 += RU) {
@@ -307,6 +179,27 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
             const int r = r0 + q;
             if (r >= nr) break;  // wave-uniform
             const float rm = rmax[r], rs = rsum[r], rinv = 1.0f / rs;
+            if (CAND) {
+                const float rt = rthr[r];   // wave-uniform
+                const bool anyc = x[q][0] >= rt || x[q][1] >= rt || x[q][2] >= rt || x[q][3] >= rt ||
+                                  x[q][0] >= cth[0] || x[q][1] >= cth[1] || x[q][2] >= cth[2] || x[q][3] >= cth[3];
+                if (__ballot(anyc) != 0ull) {   // rare: about one (row, wave) in 43 holds its row's maximum
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u >= S || x[q][u] == NEG_FILL) continue;
+                        if (x[q][u] >= rt) {
+                            const size_t o = (size_t)b * L + i0 + r;
+                            const int slot = atomicAdd(w.rcnt + o, 1);
+                            if (slot < DS_CAND_CAP) w.rcand[o * DS_CAND_CAP + slot] = j + u; else *w.ovf = 1;
+                        }
+                        if (x[q][u] >= cth[u]) {
+                            const size_t o = (size_t)b * S + j + u;
+                            const int slot = atomicAdd(w.ccnt + o, 1);
+                            if (slot < DS_CAND_CAP) w.ccand[o * DS_CAND_CAP + slot] = i0 + r; else *w.ovf = 1;
+                        }
+                    }
+                }
+            }
             if (!want_conf && thr > 0.f) {
                 const float tau = rm + __logf(thr * rs) - 1e-2f;   // wave-uniform
                 const bool any = x[q][0] > tau || x[q][1] > tau || x[q][2] > tau || x[q][3] > tau;
@@ -460,6 +353,69 @@ static int run_compaction(const unsigned char* flags, const int64_t* jsrc, const
     return 0;
 }
 
+// guarded zero fill (the fallback sequence cannot use hipMemsetAsync: it must be a no-op when the guard is clear)
+__global__ __launch_bounds__(256) void ds_zero_kernel(unsigned long long* __restrict__ p, size_t n, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) p[t] = 0ull;
+}
+
+// exact pass 1 + statistics (+ pass 2 when `with_conf`); guard: device flag, null = run
+static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, float temperature,
+                           int recip, float thr, int want_conf, float* sim_ws, const DsWs& w, int64_t* next_idx01,
+                           float* next_conf01, int64_t* next_idx10, float* next_conf10, int B, int L, int S, int C,
+                           const int* guard, hipStream_t s) {
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    const float sqrtC = (float)sqrt((double)C);
+    const size_t gemm_lds = sizeof(float) * (4 * 32 * 65 + 2 * 2 * 128 * 3);  // >= the 2 x [128][33] operand tiles
+    // per-device attribute: set on every call (cheap), never cached in a process-wide flag
+    if (recip)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+    else
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+    {
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_GEMM, s);
+        const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
+        if (recip)
+            hipLaunchKernelGGL(ds_gemm_kernel<true>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard);
+        else
+            hipLaunchKernelGGL(ds_gemm_kernel<false>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard);
+    }
+    CASMTR_CHECK_LAUNCH();
+    {
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_REDUCE, s);
+        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L,
+                           w.rmax, w.rsum, next_idx01, next_conf01, nullptr, 0, nullptr, 0.f, nullptr, guard);
+        CASMTR_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, w.cp_a, NIB, S, B * S,
+                           w.cmax, w.csum, next_idx10, next_conf10, nullptr, 0, nullptr, 0.f, nullptr, guard);
+    }
+    CASMTR_CHECK_LAUNCH();
+    if (guard) {   // rbest / cbest hold the split pass's (invalid) results
+        hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest, (size_t)B * L, guard);
+        hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.cbest, (size_t)B * S, guard);
+        CASMTR_CHECK_LAUNCH();
+    }
+    {
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_CONF, s);
+        hipLaunchKernelGGL(ds_conf_kernel<false>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
+                           w, L, S, want_conf, thr, guard);
+    }
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+static int ds_select(const DsWs& w, float thr, int border_rm, const int32_t* valid_hw, int h0c, int w0c, int h1c, int w1c,
+                     int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches, int B, int L, int S,
+                     hipStream_t s) {
+    ProfScope ps(CASMTR_PROF_DS_SELECT, s);
+    hipLaunchKernelGGL(ds_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, thr, border_rm, valid_hw, h0c, w0c,
+                       h1c, w1c, L, S, B * L);
+    CASMTR_CHECK_LAUNCH();
+    return run_compaction(w.flags, w.jsel, w.csel, w.blk, B * L, L, 0, B, b_ids, i_ids, j_ids, mconf, n_matches, s);
+}
+
 extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1,
                                        float temperature, int recip, float thr, int border_rm, const int32_t* valid_hw,
                                        int h0c, int w0c, int h1c, int w1c, int want_conf, float* sim_ws, void* stats_ws,
@@ -470,49 +426,72 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     DsWs w;
-    ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S);
+    ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S, 0);
+    hipError_t e = hipMemsetAsync(w.rbest, 0, (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)), s);
+    if (e != hipSuccess) return (int)e;
+    int rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
+                             next_idx10, next_conf10, B, L, S, C, nullptr, s);
+    if (rc) return rc;
+    return ds_select(w, thr, border_rm, valid_hw, h0c, w0c, h1c, w1c, b_ids, i_ids, j_ids, mconf, n_matches, B, L, S, s);
+}
+
+// Same contract, stats_ws sized by casmtr_dual_softmax_split_ws_bytes.  The similarity matrix comes from the f16 matrix pipe
+// (16x the fp32 MFMA rate) as three products of a two-term f16 split of the row-normalised operands: error below 2^-15 |a||b|/(C T)
+// including the fp32 chain's own rounding, so the statistics (sums, confidences) agree with the exact path far inside the 1e-4
+// softmax tolerance.  Everything that decides an INDEX is then re-decided exactly: each entry within twice that bound of its row /
+// column maximum is a candidate, and rows / columns with more than one candidate recompute those logits with the oracle's fp32 fmaf
+// chain and take the first maximum (ds_split.hip).  More than DS_CAND_CAP candidates anywhere (degenerate inputs: duplicated or
+// all-zero feature rows) -> the exact passes run after all, behind a device-side flag: no host synchronisation either way.
+extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                                             float temperature, int recip, float thr, int border_rm, const int32_t* valid_hw,
+                                             int h0c, int w0c, int h1c, int w1c, int want_conf, float* sim_ws, void* stats_ws,
+                                             int64_t* next_idx01, float* next_conf01, int64_t* next_idx10, float* next_conf10,
+                                             int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches,
+                                             int B, int L, int S, int C, casmtr_stream_t stream) {
+    if (C % DS_BK != 0 || (mask0 == nullptr) != (mask1 == nullptr)) return CASMTR_ERR_UNSUPPORTED;
+    if (B <= 0 || L <= 0 || S <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    DsWs w;
+    ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S, C);
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
-    const float sqrtC = (float)sqrt((double)C);
-    const size_t gemm_lds = sizeof(float) * (4 * 32 * 65 + 2 * 2 * 128 * 3);  // >= the 2 x [128][33] operand tiles
-    // per-device attribute: set on every call (cheap), never cached in a process-wide flag
-    if (recip)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
-    else
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
+    hipError_t e = hipMemsetAsync(w.rbest, 0, (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)), s);
+    if (e != hipSuccess) return (int)e;
+    int rc;
+    {
+        ProfScope ps(CASMTR_PROF_DS_SPLIT, s);
+        rc = ds_split_launch(feat0, feat1, w, B, L, S, C, temperature, recip, s);
+    }
+    if (rc) return rc;
     {
         ProfScope ps(CASMTR_PROF_DS_GEMM, s);
-        const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
-        if (recip)
-            hipLaunchKernelGGL(ds_gemm_kernel<true>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
-                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB);
-        else
-            hipLaunchKernelGGL(ds_gemm_kernel<false>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
-                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB);
+        rc = ds_gemm16_launch(mask0, mask1, sim_ws, w, B, L, S, C, s);
     }
-    CASMTR_CHECK_LAUNCH();
-    prof_begin(CASMTR_PROF_DS_REDUCE, s);
-    hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L,
-                       w.rmax, w.rsum, next_idx01, next_conf01);
-    CASMTR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, w.cp_a, NIB, S, B * S,
-                       w.cmax, w.csum, next_idx10, next_conf10);
-    prof_end(CASMTR_PROF_DS_REDUCE, s);
-    CASMTR_CHECK_LAUNCH();
-    hipError_t e = hipMemsetAsync(w.rbest, 0, sizeof(unsigned long long) * (size_t)B * L, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(w.cbest, 0, sizeof(unsigned long long) * (size_t)B * S, s);
-    if (e != hipSuccess) return (int)e;
+    if (rc) return rc;
+    {
+        ProfScope ps(CASMTR_PROF_DS_REDUCE, s);
+        const float kthr = 6.103515625e-05f / temperature;   // 2 e = 2^-14 |a_i|/sqrtC max|b_j|/sqrtC / T
+        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, nullptr, NJB, L, B * L,
+                           w.rmax, w.rsum, next_idx01, next_conf01, w.na, NIB * DS_BM, w.nbmax, kthr, w.rthr, nullptr);
+        CASMTR_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, nullptr, NIB, S, B * S,
+                           w.cmax, w.csum, next_idx10, next_conf10, w.nb, NJB * DS_BN, w.namax, kthr, w.cthr, nullptr);
+        CASMTR_CHECK_LAUNCH();
+    }
     {
         ProfScope ps(CASMTR_PROF_DS_CONF, s);
-        hipLaunchKernelGGL(ds_conf_kernel, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
-                           w, L, S, want_conf, thr);
+        hipLaunchKernelGGL(ds_conf_kernel<true>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
+                           w, L, S, want_conf, thr, nullptr);
     }
     CASMTR_CHECK_LAUNCH();
-    ProfScope ps(CASMTR_PROF_DS_SELECT, s);
-    hipLaunchKernelGGL(ds_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, thr, border_rm, valid_hw, h0c, w0c,
-                       h1c, w1c, L, S, B * L);
-    CASMTR_CHECK_LAUNCH();
-    return run_compaction(w.flags, w.jsel, w.csel, w.blk, B * L, L, 0, B, b_ids, i_ids, j_ids, mconf, n_matches, s);
+    {
+        ProfScope ps(CASMTR_PROF_DS_FIX, s);
+        rc = ds_fix_launch(feat0, feat1, w, B, L, S, C, temperature, recip, next_idx01, next_idx10, s);
+        if (rc) return rc;
+        rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
+                             next_idx10, next_conf10, B, L, S, C, w.ovf, s);
+    }
+    if (rc) return rc;
+    return ds_select(w, thr, border_rm, valid_hw, h0c, w0c, h1c, w1c, b_ids, i_ids, j_ids, mconf, n_matches, B, L, S, s);
 }
 
 // =================================================================================================== window match

@@ -13,8 +13,8 @@ static std::vector<Pair> g_ev[CASMTR_PROF_COUNT];
 static std::vector<Pair> g_free;
 static Pair g_open[CASMTR_PROF_COUNT];
 
-void prof_begin(int id, hipStream_t s) {
-    if (!(g_mask >> id & 1u)) return;
+void prof_begin(int id, hipStream_t s) {   // id < 0: never timed
+    if (id < 0 || !(g_mask >> id & 1u)) return;
     Pair p;
     if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
     else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
@@ -22,7 +22,7 @@ void prof_begin(int id, hipStream_t s) {
     g_open[id] = p;
 }
 void prof_end(int id, hipStream_t s) {
-    if (!(g_mask >> id & 1u)) return;
+    if (id < 0 || !(g_mask >> id & 1u)) return;
     (void)hipEventRecord(g_open[id].b, s);
     g_ev[id].push_back(g_open[id]);
 }
@@ -34,7 +34,7 @@ static const char* kNames[CASMTR_PROF_COUNT] = {
     "ds_gemm_kernel", "ds_reduce_kernel", "ds_conf_kernel", "ds_select", "coarse_logits_kernel", "coarse_row_kernel",
     "coarse_av_kernel", "qta_fine_level[lists<=64]", "quad_attn_kernel<cascade>", "window_match_kernel", "nms_select",
     "nchw_to_tokens_kernel", "window_warp_idx_kernel", "linear_nt_kernel", "token_pool_kernel", "coarse_fused_kernel",
-    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]"};
+    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "ds_split_kernel", "ds_fix_kernel"};
 
 static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {

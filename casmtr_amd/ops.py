@@ -7,6 +7,8 @@ to the CPU.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -424,8 +426,17 @@ def window_warp_idx(idx, H, W, ws=5):
     return out
 
 
+def ds_gemm_mode():
+    """'split' (default): similarity matrix on the f16 matrix pipe + exact re-decision of near-tie indices
+    (casmtr_dual_softmax_split_fwd); 'exact': fp32 MFMA = the oracle's fmaf chain for every entry.  Read per call."""
+    m = os.environ.get("CASMTR_DS_GEMM", "split")
+    if m not in ("split", "exact"):
+        raise RuntimeError(f"CASMTR_DS_GEMM={m!r}: expected 'split' or 'exact'")
+    return m
+
+
 def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=None, mask1=None, valid_hw=None,
-                 recip=True, want_conf=True):
+                 recip=True, want_conf=True, gemm=None):
     """CoarseMatching numerics.  Returns a dict; match lists are capacity-sized, `n` is a device int64 scalar."""
     _chk(feat0, "feat0"), _chk(feat1, "feat1")
     mask0, mask1 = _u8(mask0), _u8(mask1)
@@ -434,8 +445,11 @@ def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=No
     S = feat1.shape[1]
     dev = feat0.device
     l = _lib.lib()
+    split = (gemm or ds_gemm_mode()) == "split"
     sim = torch.empty((B, L, S), device=dev, dtype=torch.float32)
-    ws = torch.empty(l.casmtr_dual_softmax_ws_bytes(B, L, S), device=dev, dtype=torch.uint8)
+    ws = torch.empty(l.casmtr_dual_softmax_split_ws_bytes(B, L, S, Cc) if split else l.casmtr_dual_softmax_ws_bytes(B, L, S),
+                     device=dev, dtype=torch.uint8)
+    fwd = l.casmtr_dual_softmax_split_fwd if split else l.casmtr_dual_softmax_fwd
     ni01 = torch.empty((B, L), device=dev, dtype=torch.int64)
     nc01 = torch.empty((B, L), device=dev, dtype=torch.float32)
     ni10 = torch.empty((B, S), device=dev, dtype=torch.int64)
@@ -444,12 +458,12 @@ def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=No
     mc = torch.empty(B * L, device=dev, dtype=torch.float32)
     n = torch.zeros(1, device=dev, dtype=torch.int64)
     with torch.cuda.device(dev):
-        _lib.check(l.casmtr_dual_softmax_fwd(_ptr(feat0), _ptr(feat1), _ptr(mask0), _ptr(mask1), float(temperature),
-                                             int(bool(recip)), float(thr), int(border_rm), _ptr(valid_hw), hw0[0], hw0[1],
-                                             hw1[0], hw1[1], int(bool(want_conf)), _ptr(sim), _ptr(ws), _ptr(ni01),
-                                             _ptr(nc01), _ptr(ni10), _ptr(nc10), _ptr(bi), _ptr(ii), _ptr(ji), _ptr(mc),
-                                             _ptr(n), B, L, S, Cc, _stream()), "dual_softmax_fwd")
-    return dict(conf_matrix=sim if want_conf else None, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
+        _lib.check(fwd(_ptr(feat0), _ptr(feat1), _ptr(mask0), _ptr(mask1), float(temperature),
+                       int(bool(recip)), float(thr), int(border_rm), _ptr(valid_hw), hw0[0], hw0[1],
+                       hw1[0], hw1[1], int(bool(want_conf)), _ptr(sim), _ptr(ws), _ptr(ni01),
+                       _ptr(nc01), _ptr(ni10), _ptr(nc10), _ptr(bi), _ptr(ii), _ptr(ji), _ptr(mc),
+                       _ptr(n), B, L, S, Cc, _stream()), "dual_softmax_fwd")
+    return dict(conf_matrix=sim if want_conf else None, sim=None if want_conf else sim, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
                 next_conf_c10=nc10, b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n)
 
 

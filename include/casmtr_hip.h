@@ -157,6 +157,19 @@ int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, const uint8_
                             int B, int L, int S, int C, casmtr_stream_t stream);
 size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S);
 
+/* Same contract and results (indices identical, probabilities within the softmax tolerance); stats_ws sized by
+ * casmtr_dual_softmax_split_ws_bytes.  The similarity matrix is computed on the f16 matrix pipe as three products of a two-term
+ * f16 split of the row-normalised operands (error < 2^-15 |a||b|/(C T)); every entry within twice that bound of its row / column
+ * maximum is re-evaluated with the exact fp32 fmaf chain before an index is decided, and inputs with more than 8 such entries in a
+ * row or column (duplicated / all-zero feature rows) run the exact passes of casmtr_dual_softmax_fwd behind a device-side flag. */
+int casmtr_dual_softmax_split_fwd(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1,
+                                  float temperature, int recip, float thr, int border_rm, const int32_t* valid_hw,
+                                  int h0c, int w0c, int h1c, int w1c, int want_conf, float* sim_ws, void* stats_ws,
+                                  int64_t* next_idx01, float* next_conf01, int64_t* next_idx10, float* next_conf10,
+                                  int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches,
+                                  int B, int L, int S, int C, casmtr_stream_t stream);
+size_t casmtr_dual_softmax_split_ws_bytes(int B, int L, int S, int C);
+
 /* CascadeMatching.forward, one direction per call (src/model/functions/cascade_matching.py:63-161).
  *   feat_q [B,N,C], feat_k [B,M,C], idx [B,N,K]; mask_q [B,N] / mask_k [B,M] uint8 or NULL;
  *   (h,w): the query grid, used only to let the 4 children of a quad share their (identical) window rows;
@@ -262,7 +275,7 @@ enum {
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
     CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED,
-    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_COUNT
+    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_DS_SPLIT, CASMTR_PROF_DS_FIX, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
 /* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).

@@ -1,0 +1,131 @@
+"""Split dual-softmax (casmtr_dual_softmax_split_fwd, csrc/ds_split.hip): the similarity matrix comes from the f16 matrix pipe, the
+indices must still be the oracle's.  CoarseMatching.forward, src/model/functions/coarse_matching.py:59-89.
+
+  * error bound: |sim_split - sim_exact| <= 2^-15 |a_i||b_j|/(C T) is what the candidate margin assumes; measured here with a
+    factor 8 to spare, on random, badly scaled and sparse rows;
+  * near ties: columns that differ from another column by a few ulp in one channel -> several candidates per row, the exact chain
+    decides; the result must be the oracle's first maximum;
+  * overflow: more than DS_CAND_CAP equal rows -> the device-side fallback to the exact passes;
+  * masks: fully masked rows / columns answer index 0 (first of the equal -1e9 entries).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+N = lambda t: t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from casmtr_amd import ops as o
+    return o
+
+
+def _features(kind, r, B, L, C):
+    f = r.standard_normal((B, L, C), dtype=np.float32)
+    if kind == "scaled":      # rows spanning 7 orders of magnitude, a few huge / tiny channels inside a row
+        f *= np.exp(r.uniform(-10, 6, (B, L, 1))).astype(np.float32)
+        f[:, :, 3] *= 300.0
+        f[:, :, 7] *= 1e-4
+    elif kind == "sparse":    # most channels exactly zero
+        f *= (r.random((B, L, C)) < 0.1)
+    return np.ascontiguousarray(f, dtype=np.float32)
+
+
+@pytest.mark.parametrize("kind", ["randn", "scaled", "sparse"])
+def test_split_error_bound(ops, kind):
+    r = np.random.default_rng(11)
+    B, h, w, C, Tm = 2, 24, 20, 256, 0.1      # 480 tokens: 4 row blocks, the last one partial
+    f0, f1 = _features(kind, r, B, h * w, C), _features(kind, r, B, h * w, C)
+    ex = ops.dual_softmax(T(f0), T(f1), (h, w), (h, w), Tm, 0.2, want_conf=False, gemm="exact")
+    sp = ops.dual_softmax(T(f0), T(f1), (h, w), (h, w), Tm, 0.2, want_conf=False, gemm="split")
+    na = np.linalg.norm(f0.astype(np.float64) / 16.0, axis=2)
+    nb = np.linalg.norm(f1.astype(np.float64) / 16.0, axis=2)
+    bound = 2.0 ** -15 * na[:, :, None] * nb[:, None, :] / Tm
+    err = np.abs(N(sp["sim"]).astype(np.float64) - N(ex["sim"]).astype(np.float64))
+    ratio = (err / np.maximum(bound, 1e-300)).max()
+    assert ratio < 0.125, f"{kind}: split error is {ratio:.3f} of the candidate margin's bound"
+    assert torch.equal(sp["next_idx_c01"], ex["next_idx_c01"]) and torch.equal(sp["next_idx_c10"], ex["next_idx_c10"])
+    if kind != "scaled":   # logits of 1e6 and more: their fp32 rounding alone moves the probabilities, in either path
+        assert np.abs(N(sp["next_conf_c01"]) - N(ex["next_conf_c01"])).max() < 1e-5
+
+
+def _near_duplicates(r, f, ndup, copies):
+    """rows of f[0] copied `copies` times with one channel moved by 0..2 ulp (equal, or separated far below the split error)"""
+    L, C = f.shape[1:]
+    for _ in range(ndup):
+        src = int(r.integers(0, L))
+        for dst in r.choice(L, copies, replace=False):
+            f[0, dst] = f[0, src]
+            c = int(r.integers(0, C))
+            for _ in range(int(r.integers(0, 3))):
+                f[0, dst, c] = np.nextafter(f[0, dst, c], np.float32(np.inf))
+    return f
+
+
+@pytest.mark.parametrize("recip", [False, True])
+@pytest.mark.parametrize("copies,masks", [(2, False), (5, True), (12, False)])
+def test_split_near_ties_and_overflow(ops, copies, masks, recip):
+    """copies = 2, 5: candidate lists of 3-6 entries, decided by the exact chain; 12: more than DS_CAND_CAP -> exact fallback"""
+    r = np.random.default_rng(100 + copies)
+    h, w, C = 16, 18, 256
+    L = h * w
+    f0 = _near_duplicates(r, r.standard_normal((1, L, C), dtype=np.float32), 20, copies)
+    f1 = _near_duplicates(r, r.standard_normal((1, L, C), dtype=np.float32), 20, copies)
+    m0 = m1 = valid = None
+    if masks:
+        mm0, mm1 = np.ones((1, h, w), bool), np.ones((1, h, w), bool)
+        mm0[:, 13:], mm0[:, :, 15:] = False, False
+        mm1[:, 12:], mm1[:, :, 16:] = False, False
+        m0, m1 = mm0.reshape(1, -1), mm1.reshape(1, -1)
+        valid = np.array([[13, 15, 12, 16]], np.int32)
+    o = oracle.dual_softmax(f0, f1, (h, w), (h, w), 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, recip=recip)
+    tm = lambda m: None if m is None else T(m)
+    d = ops.dual_softmax(T(f0), T(f1), (h, w), (h, w), 0.1, 0.2, mask0=tm(m0), mask1=tm(m1), valid_hw=tm(valid), recip=recip,
+                         want_conf=False, gemm="split")
+    assert np.array_equal(N(d["next_idx_c01"]), o["next_idx_c01"])
+    assert np.array_equal(N(d["next_idx_c10"]), o["next_idx_c10"])
+    assert np.abs(N(d["next_conf_c01"]) - o["next_conf_c01"]).max() < 1e-5
+    assert np.abs(N(d["next_conf_c10"]) - o["next_conf_c10"]).max() < 1e-5
+    n = int(d["n"].item())
+    assert n == len(o["i_ids"]) and np.array_equal(N(d["i_ids"][:n]), o["i_ids"]) and np.array_equal(N(d["j_ids"][:n]), o["j_ids"])
+
+
+def test_split_degenerate_inputs(ops):
+    """all-zero features: every entry ties -> overflow -> exact passes; index 0 everywhere, uniform probabilities"""
+    h, w, C = 12, 12, 64
+    z = torch.zeros((1, h * w, C), device=DEV)
+    d = ops.dual_softmax(z, z, (h, w), (h, w), 0.1, 0.2, want_conf=True, gemm="split")
+    assert int(d["next_idx_c01"].abs().max()) == 0 and int(d["next_idx_c10"].abs().max()) == 0
+    assert torch.allclose(d["next_conf_c01"], torch.full_like(d["next_conf_c01"], 1.0 / (h * w)))
+    assert torch.allclose(d["conf_matrix"], torch.full_like(d["conf_matrix"], 1.0 / (h * w) ** 2))
+
+
+def test_split_full_size_vs_exact(ops):
+    """832x832 grid (104^2 tokens, C = 256), two pairs, 20 % padding masks on the second call: the two GEMM paths agree on every
+    index and to 1e-6 on the probabilities; match lists identical."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, h, C = 2, 104, 256
+    f0 = torch.randn((B, h * h, C), generator=g).to(DEV)
+    f1 = torch.randn((B, h * h, C), generator=g).to(DEV)
+    for masked in (False, True):
+        m0 = m1 = valid = None
+        if masked:
+            m = torch.ones((B, h, h), dtype=torch.bool)
+            m[:, 83:], m[:, :, 90:] = False, False
+            m0 = m1 = m.reshape(B, -1).to(DEV)
+            valid = torch.tensor([[83, 90, 83, 90]] * B, dtype=torch.int32, device=DEV)
+        ex = ops.dual_softmax(f0, f1, (h, h), (h, h), 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, want_conf=False, gemm="exact")
+        sp = ops.dual_softmax(f0, f1, (h, h), (h, h), 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, want_conf=False, gemm="split")
+        assert torch.equal(sp["next_idx_c01"], ex["next_idx_c01"]) and torch.equal(sp["next_idx_c10"], ex["next_idx_c10"])
+        assert float((sp["next_conf_c01"] - ex["next_conf_c01"]).abs().max()) < 1e-6
+        assert float((sp["next_conf_c10"] - ex["next_conf_c10"]).abs().max()) < 1e-6
+        n = int(sp["n"].item())
+        assert n == int(ex["n"].item())
+        assert torch.equal(sp["i_ids"][:n], ex["i_ids"][:n]) and torch.equal(sp["j_ids"][:n], ex["j_ids"][:n])
+        assert float((sp["mconf"][:n] - ex["mconf"][:n]).abs().max()) < 1e-6 if n else True

@@ -242,9 +242,10 @@ def _valid_hw(m0, m1):
     return np.stack([m0.sum(1).max(-1), m0.sum(2).max(-1), m1.sum(1).max(-1), m1.sum(2).max(-1)], 1).astype(np.int32)
 
 
+@pytest.mark.parametrize("gemm", ["split", "exact"])
 @pytest.mark.parametrize("recip", [False, True])
 @pytest.mark.parametrize("name", list(CASES["coarse_matching"]))
-def test_dual_softmax(ops, name, recip):
+def test_dual_softmax(ops, name, recip, gemm):
     inp = make_inputs("coarse_matching", name)
     cfg = CASES["coarse_matching"][name]
     B = cfg["B"]
@@ -257,7 +258,7 @@ def test_dual_softmax(ops, name, recip):
                             recip=recip, want_conf=True, **kw)
     d = ops.dual_softmax(T(inp["feat0"]), T(inp["feat1"]), cfg["hw0"], cfg["hw1"], mask0=None if m0 is None else T(m0),
                          mask1=None if m1 is None else T(m1), valid_hw=None if valid is None else T(valid), recip=recip,
-                         want_conf=True, **kw)
+                         want_conf=True, gemm=gemm, **kw)
     assert np.array_equal(N(d["next_idx_c01"]), o["next_idx_c01"]), "row argmax must be bit-exact"
     assert np.array_equal(N(d["next_idx_c10"]), o["next_idx_c10"]), "column argmax must be bit-exact"
     assert_close(N(d["next_conf_c01"]), o["next_conf_c01"], SOFTMAX_TOL, "next_conf_c01")

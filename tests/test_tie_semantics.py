@@ -70,10 +70,11 @@ def test_gpu_ties_bit_exact_vs_oracle():
     # dual softmax: duplicated rows on both sides -> tied row and column maxima
     f0 = _dup_features(r, 1, 16 * 16, 256, 60)
     f1 = f0[:, r.permutation(256)].copy()
-    dd = ops.dual_softmax(T(f0), T(f1), (16, 16), (16, 16), 0.1, 0.2, recip=True, want_conf=False)
     oo = oracle.dual_softmax(f0, f1, (16, 16), (16, 16), 0.1, 0.2, recip=True)
-    assert np.array_equal(dd["next_idx_c01"].cpu().numpy(), oo["next_idx_c01"])
-    assert np.array_equal(dd["next_idx_c10"].cpu().numpy(), oo["next_idx_c10"])
+    for gemm in ("split", "exact"):
+        dd = ops.dual_softmax(T(f0), T(f1), (16, 16), (16, 16), 0.1, 0.2, recip=True, want_conf=False, gemm=gemm)
+        assert np.array_equal(dd["next_idx_c01"].cpu().numpy(), oo["next_idx_c01"]), gemm
+        assert np.array_equal(dd["next_idx_c10"].cpu().numpy(), oo["next_idx_c10"]), gemm
     # quadtree levels: duplicated key rows -> tied logits inside the top-k
     H, D = 8, 32
     q = r.standard_normal((1, 16 * 16, H * D), dtype=np.float32)
