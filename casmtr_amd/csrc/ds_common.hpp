@@ -30,6 +30,7 @@ struct DsWs {  // carve of stats_ws
     float *na, *nb;                  // [B][Lp], [B][Sp] |row| / sqrt(C), rounded up
     float *fa, *fb;                  // [B][Lp], [B][Sp] epilogue factors (2^e / (C T), 2^e)
     float *rthr, *cthr;              // [B*L], [B*S] candidate thresholds
+    float* cg_m;                     // [B][NIB][8][S] column maxima of the 16-row groups (wr, ti, hi) of each 128-row block
     int *rcand, *ccand;              // [B*L][CAP], [B*S][CAP]
     _Float16 *imgA, *imgB;           // tile images [B][NIB][C/32][4 kg][2 parts][128 rows][8]
 };
@@ -62,6 +63,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
         CARVE(na, float, (size_t)B * Lp); CARVE(nb, float, (size_t)B * Sp);
         CARVE(fa, float, (size_t)B * Lp); CARVE(fb, float, (size_t)B * Sp);
         CARVE(rthr, float, (size_t)B * L); CARVE(cthr, float, (size_t)B * S);
+        CARVE(cg_m, float, (size_t)B * NIB * 8 * S);
         CARVE(rcand, int, (size_t)B * L * DS_CAND_CAP); CARVE(ccand, int, (size_t)B * S * DS_CAND_CAP);
         CARVE(imgA, _Float16, (size_t)B * Lp * C * 2); CARVE(imgB, _Float16, (size_t)B * Sp * C * 2);
     }
@@ -76,8 +78,9 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
 //   2. column (max, [first argmax,] sum exp) over the wave's 64 rows: in-lane scan + one xor-32 exchange;
 //   3. row statistics over the wave's 64 columns: 32-row slabs through a wave-private LDS region, lane <-> row;
 //   4. the two waves sharing rows / columns combine through a small LDS exchange -> one partial per 128-wide block.
-// SPLIT: x = acc * facA[row] * facB[col] (factors staged in LDS), no argmax tracking (the indices come from the exact
-// re-decision of the near-tie candidates); otherwise x = acc / T and the first argmax is tracked.
+// SPLIT: x = acc * facA[row] * facB[col] (factors staged in LDS), no row argmax (the indices come from the exact re-decision of
+// the near-tie candidates), but the column maxima of the eight 16-row groups of the block are kept (cg_m); otherwise
+// x = acc / T and the first argmax is tracked in both directions.
 // `scratch` >= 4*32*65 + 2*2*128*3 floats, free of live data (caller has synchronised the workgroup).
 template <bool RECIP, bool SPLIT>
 __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scratch, const float* facA, const float* facB,
@@ -123,13 +126,23 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
     for (int tj = 0; tj < 2; ++tj) {
         float m = -INFINITY; int am = 0;
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < 2; ++ti) {
+            if (SPLIT) {
+                // maximum of this lane's 16-row group (wr, ti, hi): lets the sparse pass 2 read 16 rows of a column, not 128
+                float g16 = acc[ti][tj][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {  // (ti, r>>2, r&3) ascending == row ascending for this half-wave
-                const float x = acc[ti][tj][r];
-                if (SPLIT) m = fmaxf(m, x);
-                else if (x > m) { m = x; am = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+                for (int r = 1; r < 16; ++r) g16 = fmaxf(g16, acc[ti][tj][r]);
+                const int gj = j0 + wc * 64 + tj * 32 + ln;
+                if (gj < S) w.cg_m[(((size_t)b * NIB + tI) * 8 + wr * 4 + ti * 2 + hi) * S + gj] = g16;
+                m = fmaxf(m, g16);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {  // (ti, r>>2, r&3) ascending == row ascending for this half-wave
+                    const float x = acc[ti][tj][r];
+                    if (x > m) { m = x; am = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
+                }
             }
+        }
         const float pm = __shfl_xor(m, 32);
         if (SPLIT) m = fmaxf(m, pm);
         else {
@@ -214,6 +227,7 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
 int ds_split_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
                     hipStream_t s);
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s);
+int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, hipStream_t s);
 int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
                   int64_t* next_idx01, int64_t* next_idx10, hipStream_t s);
 

@@ -111,17 +111,25 @@ __device__ __forceinline__ void glds_4k(const char* base, unsigned voff, unsigne
                  :: "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
-// 128 x 128 block tile, 4 waves x (64 x 64), k-stages of 32 (16 KB of A image + 16 KB of B image), double buffered: the DMA
-// of stage ks+1 is in flight while stage ks feeds 24 MFMAs per wave.  2 workgroups per CU (2 x 65 KB LDS): one workgroup's
-// epilogue (VALU / LDS / stores) overlaps the other's MFMA loop.
-#define DS16_STAGE 32768
-__global__ __launch_bounds__(256, 2) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
+__device__ __forceinline__ void glds_2k(const char* base, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024"
+                 :: "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// 128 x 128 block tile, 4 waves x (64 x 64), k-stages of 16 (8 KB of A image + 8 KB of B image = half a 16 KB image chunk),
+// double buffered: the DMA of stage ks+1 is in flight while stage ks feeds 12 MFMAs per wave.  40 KB of LDS -> 4 workgroups
+// per CU, 4 waves per SIMD: other workgroups' MFMA loops run under a workgroup's epilogue (VALU / LDS / stores).
+#define DS16_STAGE 16384
+#define DS16_LDS (4 * 32 * 65 * 4 + 2 * 2 * 128 * 3 * 4 + 2 * 128 * 4)   // epilogue scratch (aliases the stages) + factors
+__global__ __launch_bounds__(256, 4) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
-                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B), then facA[128] | facB[128]
+                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
     char* lds = reinterpret_cast<char*>(smem);
-    float* facA = smem + 2 * DS16_STAGE / 4;
+    float* facA = smem + (DS16_LDS - 2 * 128 * 4) / 4;
     float* facB = facA + 128;
     const int NSJ = (NJB + 7) >> 3;
     const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
@@ -140,63 +148,174 @@ __global__ __launch_bounds__(256, 2) void ds_gemm16_kernel(const _Float16* __res
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const char* a_src = uniform_ptr(reinterpret_cast<const char*>(imgA) + ((size_t)b * NIB + tI) * (size_t)KS * 16384);
-    const char* b_src = uniform_ptr(reinterpret_cast<const char*>(imgB) + ((size_t)b * NJB + tJ) * (size_t)KS * 16384);
-    const unsigned voff = (unsigned)(wave * 4096 + lane * 16);
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_byte_addr(lds) + (unsigned)(wave * 4096)));
+    const char* a_src = uniform_ptr(reinterpret_cast<const char*>(imgA) + ((size_t)b * NIB + tI) * (size_t)KS * 8192);
+    const char* b_src = uniform_ptr(reinterpret_cast<const char*>(imgB) + ((size_t)b * NJB + tJ) * (size_t)KS * 8192);
+    const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_byte_addr(lds) + (unsigned)(wave * 2048)));
     __syncthreads();   // the factor loads above have completed (compiler-counted) before any DMA is outstanding
-    glds_4k(a_src, voff, lds0);
-    glds_4k(b_src, voff, lds0 + 16384);
+    glds_2k(a_src, voff, lds0);
+    glds_2k(b_src, voff, lds0 + 8192);
     const int hi = lane >> 5, ln = lane & 31;
-    // fragment (ti, part) of sub-step `sub`: plane (kg = 2 sub + hi, part), row wr*64 + ti*32 + ln
+    // fragment (ti, part): plane (kg = hi, part), row wr*64 + ti*32 + ln
     const char* fa_base = lds + (hi * 2) * 2048 + (wr * 64 + ln) * 16;
-    const char* fb_base = lds + 16384 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
+    const char* fb_base = lds + 8192 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
     for (int ks = 0; ks < KS; ++ks) {
         glds_wait<0>();
         __syncthreads();   // stage ks has landed for every wave; everyone is done reading the other buffer
         const int buf = ks & 1;
         if (ks + 1 < KS) {
-            glds_4k(a_src + (size_t)(ks + 1) * 16384, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE));
-            glds_4k(b_src + (size_t)(ks + 1) * 16384, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE) + 16384);
+            glds_2k(a_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE));
+            glds_2k(b_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE) + 8192);
         }
+        h16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            h16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const char* pa = fa_base + buf * DS16_STAGE + sub * 8192 + ti * 512;
-                const char* pb = fb_base + buf * DS16_STAGE + sub * 8192 + ti * 512;
-                ah[ti] = *reinterpret_cast<const h16x8*>(pa);
-                al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
-                bh[ti] = *reinterpret_cast<const h16x8*>(pb);
-                bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
-            }
-            // small terms first; every accumulator is touched again only after three other MFMAs
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+        for (int ti = 0; ti < 2; ++ti) {
+            const char* pa = fa_base + buf * DS16_STAGE + ti * 512;
+            const char* pb = fb_base + buf * DS16_STAGE + ti * 512;
+            ah[ti] = *reinterpret_cast<const h16x8*>(pa);
+            al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
+            bh[ti] = *reinterpret_cast<const h16x8*>(pb);
+            bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
         }
+        // small terms first; every accumulator is touched again only after three other MFMAs
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
+    if (dbg & 1) { if (acc[0][0][0] == 123.456f) sim[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
     ds_tile_epilogue<true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
 }
 
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
-    const size_t lds = 2 * DS16_STAGE + 2 * 128 * sizeof(float);
+    const size_t lds = DS16_LDS;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
     hipLaunchKernelGGL(ds_gemm16_kernel, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
-                       C / 32, NJB, NIB);
+                       C / 16, NJB, NIB, getenv("DS16_DBG") ? atoi(getenv("DS16_DBG")) : 0);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================== sparse pass 2
+// The dense pass 2 (ds_conf_kernel) streams the whole matrix to find the few entries that matter: those at or above their row's /
+// column's near-tie threshold (index candidates) and those whose confidence can exceed `thr` (conf = p01 p10 > thr needs
+// p01 > thr, i.e. x > rmax + log(thr rsum) = tau).  The GEMM epilogue already left the maximum of every (row, 128-column block)
+// and (column, 128-row block) segment in rp_m / cp_m, and a segment whose maximum is below the threshold holds no such entry --
+// on matching features that is all but one or two of a row's 85 segments.  One wave per 64 rows (lane <-> row while the
+// segment maxima stream past, coalesced); every flagged (row, block) segment is then read by the whole wave (512 B).  Column
+// segments (128 rows x one column, strided) only look for index candidates: every entry with conf > thr sits in a flagged ROW
+// segment, which also feeds the column-best atomics.  Same candidate lists and best-of-row / best-of-column keys as the dense pass.
+#define DS_SP_CHUNK 8
+__global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict__ sim, DsWs w, int B, int L, int S, int NJB, int NIB,
+                                                        float thr, int dbg) {
+    const int lane = threadIdx.x & 63;
+    const int gw0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int RG = (L + 63) / 64, CG = (S + 63) / 64;
+    const int RCH = (NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK, CCH = (NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK;   // block chunks per wave
+    if (gw0 < B * RG * RCH) {
+        if (dbg & 1) return;
+        const int gw = gw0 / RCH, t0 = (gw0 % RCH) * DS_SP_CHUNK;
+        const int b = gw / RG, g = gw % RG, i = g * 64 + lane;
+        const bool ok = i < L;
+        const size_t ro = (size_t)b * L + (ok ? i : L - 1);
+        const float rm = w.rmax[ro], rs = w.rsum[ro], rt = w.rthr[ro];
+        const float tau = rm + __logf(thr * rs) - 1e-2f, rinv = 1.0f / rs;
+        const float lim = fminf(rt, tau);
+        float mv[DS_SP_CHUNK];
+#pragma unroll
+        for (int k = 0; k < DS_SP_CHUNK; ++k)   // all loads in flight before the first use
+            mv[k] = w.rp_m[((size_t)b * NJB + min(t0 + k, NJB - 1)) * L + (ok ? i : L - 1)];
+#pragma unroll
+        for (int k = 0; k < DS_SP_CHUNK; ++k) {
+            const int tJ = t0 + k;
+            const float m = mv[k];
+            unsigned long long bal = __ballot(ok && tJ < NJB && m >= lim && m != NEG_FILL);
+            if (dbg & 4) bal = 0;
+            while (bal) {
+                const int l = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                const int r = g * 64 + l;
+                const float rm_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), l));
+                const float rt_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rt), l));
+                const float tau_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tau), l));
+                const float rinv_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv), l));
+                const size_t o = (size_t)b * L + r;
+                const float* p = sim + o * S;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = tJ * DS_BN + lane + 64 * u;
+                    if (j >= S) continue;
+                    const float x = p[j];
+                    if (x == NEG_FILL) continue;
+                    if (x >= rt_l) {
+                        const int slot = atomicAdd(w.rcnt + o, 1);
+                        if (slot < DS_CAND_CAP) w.rcand[o * DS_CAND_CAP + slot] = j; else *w.ovf = 1;
+                    }
+                    if (x > tau_l) {
+                        const size_t co = (size_t)b * S + j;
+                        const float cf = (__expf(x - w.cmax[co]) * (1.0f / w.csum[co])) * (__expf(x - rm_l) * rinv_l);
+                        if (cf >= 0.f) {
+                            const unsigned long long hi = (unsigned long long)__float_as_uint(cf) << 32;
+                            atomicMax(w.rbest + o, hi | (0xFFFFFFFFu - (unsigned)j));
+                            atomicMax(w.cbest + co, hi | (0xFFFFFFFFu - (unsigned)r));
+                        }
+                    }
+                }
+            }
+        }
+    } else if (gw0 < B * RG * RCH + B * CG * CCH) {
+        const int gc0 = gw0 - B * RG * RCH;
+        if (dbg & 2) return;
+        const int gc = gc0 / CCH, t0 = (gc0 % CCH) * DS_SP_CHUNK;
+        const int b = gc / CG, g = gc % CG, j = g * 64 + lane;
+        const bool ok = j < S;
+        const float ct = w.cthr[(size_t)b * S + (ok ? j : S - 1)];
+        float mv[DS_SP_CHUNK];
+#pragma unroll
+        for (int k = 0; k < DS_SP_CHUNK; ++k)
+            mv[k] = w.cp_m[((size_t)b * NIB + min(t0 + k, NIB - 1)) * S + (ok ? j : S - 1)];
+#pragma unroll
+        for (int k = 0; k < DS_SP_CHUNK; ++k) {
+            const int tI = t0 + k;
+            const float m = mv[k];
+            unsigned long long bal = __ballot(ok && tI < NIB && m >= ct && m != NEG_FILL);
+            while (bal) {
+                const int l = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                const int col = g * 64 + l;
+                const float ct_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ct), l));
+                const size_t co = (size_t)b * S + col;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    // row lane + 64 u of the block belongs to the 16-row group (wr = u, ti = lane >> 5, hi = (lane >> 2) & 1)
+                    const int i = tI * DS_BM + lane + 64 * u;
+                    const float gm = w.cg_m[(((size_t)b * NIB + tI) * 8 + u * 4 + (lane >> 5) * 2 + ((lane >> 2) & 1)) * S + col];
+                    if (i >= L || !(gm >= ct_l)) continue;
+                    const float x = sim[((size_t)b * L + i) * S + col];
+                    if (x == NEG_FILL || !(x >= ct_l)) continue;
+                    const int slot = atomicAdd(w.ccnt + co, 1);
+                    if (slot < DS_CAND_CAP) w.ccand[co * DS_CAND_CAP + slot] = i; else *w.ovf = 1;
+                }
+            }
+        }
+    }
+}
+
+int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, hipStream_t s) {
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    const int waves = B * ((L + 63) / 64) * ((NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK) + B * ((S + 63) / 64) * ((NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK);
+    hipLaunchKernelGGL(ds_sparse_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, sim, w, B, L, S, NJB, NIB, thr, getenv("DS_SP_DBG") ? atoi(getenv("DS_SP_DBG")) : 0);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }

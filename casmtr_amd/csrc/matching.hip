@@ -479,8 +479,12 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     }
     {
         ProfScope ps(CASMTR_PROF_DS_CONF, s);
-        hipLaunchKernelGGL(ds_conf_kernel<true>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
-                           w, L, S, want_conf, thr, nullptr);
+        if (!want_conf && thr >= 1e-3f) {   // segment-sparse pass 2 (the dense one is needed only to write conf_matrix)
+            rc = ds_sparse_launch(sim_ws, w, B, L, S, thr, s);
+            if (rc) return rc;
+        } else
+            hipLaunchKernelGGL(ds_conf_kernel<true>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
+                               w, L, S, want_conf, thr, nullptr);
     }
     CASMTR_CHECK_LAUNCH();
     {
