@@ -34,50 +34,70 @@ __global__ __launch_bounds__(256) void ds_split_kernel(const float* __restrict__
     const int rb = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = NRB * 128;
     float wmax = 0.f;
-    for (int rr = 0; rr < 32; ++rr) {
-        const int r = wave * 32 + rr, gi = rb * 128 + r;
-        float mx = 0.f, ss = 0.f;
-        if (gi < N) {
-            const float* p = f + ((size_t)b * N + gi) * C;
-            for (int c = lane * 4; c < C; c += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    // 8 rows per step: their loads are all in flight before the first reduction (a row at a time is one exposed HBM round
+    // trip per row, 32 in a row per wave)
+    for (int rr0 = 0; rr0 < 32; rr0 += 8) {
+        float mx[8], ss[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int gi = rb * 128 + wave * 32 + rr0 + q;
+            mx[q] = 0.f; ss[q] = 0.f;
+            if (gi < N) {
+                const float* p = f + ((size_t)b * N + gi) * C;
+                for (int c = lane * 4; c < C; c += 256) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+                    mx[q] = fmaxf(fmaxf(mx[q], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    ss[q] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
             }
         }
-        mx = wave_max_f32(mx);
-        ss = wave_sum_f32(ss);
-        // largest element -> [512, 1024): products < 2^20, 256-term sums < 2^28, f16 hi parts far from 65504
-        const int e = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
-        // |a| / sqrt(C), rounded up: 1.001 covers the fp32 summation (<= C 2^-24 relative) and the square root
-        const float nr = sqrtf(ss) * inv_sqrtC * 1.001f;
-        if (lane == 0) {
-            ex[r] = e;
-            fac[(size_t)b * Np + gi] = gi < N ? ldexpf(k0, e) : 0.f;
-            nrm[(size_t)b * Np + gi] = gi < N ? nr : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = wave * 32 + rr0 + q, gi = rb * 128 + r;
+            const float m = wave_max_f32(mx[q]);
+            const float s2 = wave_sum_f32(ss[q]);
+            // largest element -> [512, 1024): products < 2^20, 256-term sums < 2^28, f16 hi parts far from 65504
+            const int e = (m > 0.f && m < INFINITY) ? ilogbf(m) - 9 : 0;
+            // |a| / sqrt(C), rounded up: 1.001 covers the fp32 summation (<= C 2^-24 relative) and the square root
+            const float nr = sqrtf(s2) * inv_sqrtC * 1.001f;
+            if (lane == 0) {
+                ex[r] = e;
+                fac[(size_t)b * Np + gi] = gi < N ? ldexpf(k0, e) : 0.f;
+                nrm[(size_t)b * Np + gi] = gi < N ? nr : 0.f;
+            }
+            if (gi < N) wmax = fmaxf(wmax, nr);
         }
-        if (gi < N) wmax = fmaxf(wmax, nr);
     }
     if (lane == 0 && wmax > 0.f) atomicMax(nmax + b, __float_as_uint(wmax));
     __syncthreads();
     const int r = tid & 127, gi = rb * 128 + r, e = ex[r];
     const float* p = f + ((size_t)b * N + (gi < N ? gi : N - 1)) * C;
     char* out = reinterpret_cast<char*>(img) + ((size_t)b * NRB + rb) * (size_t)(C / 32) * 16384 + r * 16;
-    for (int g = tid >> 7; g < C / 8; g += 2) {
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(p + 8 * g), v1 = *reinterpret_cast<const f32x4*>(p + 8 * g + 4);
-        if (gi >= N) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        h16x8 hi, lo;
+    for (int g0 = tid >> 7; g0 < C / 8; g0 += 8) {   // 4 k-groups per step: 8 loads in flight
+        f32x4 v[4][2];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float xn = ldexpf(x[c], -e);
-            const _Float16 h = (_Float16)xn;
-            hi[c] = h;
-            lo[c] = (_Float16)(xn - (float)h);
+        for (int q = 0; q < 4; ++q) {
+            const int g = min(g0 + 2 * q, C / 8 - 1);
+            v[q][0] = *reinterpret_cast<const f32x4*>(p + 8 * g);
+            v[q][1] = *reinterpret_cast<const f32x4*>(p + 8 * g + 4);
         }
-        char* o = out + (size_t)(g >> 2) * 16384 + (g & 3) * 4096;
-        *reinterpret_cast<h16x8*>(o) = hi;
-        *reinterpret_cast<h16x8*>(o + 2048) = lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = g0 + 2 * q;
+            if (g >= C / 8) break;
+            const float x[8] = {v[q][0].x, v[q][0].y, v[q][0].z, v[q][0].w, v[q][1].x, v[q][1].y, v[q][1].z, v[q][1].w};
+            h16x8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float xn = gi < N ? ldexpf(x[c], -e) : 0.f;
+                const _Float16 h = (_Float16)xn;
+                hi[c] = h;
+                lo[c] = (_Float16)(xn - (float)h);
+            }
+            char* o = out + (size_t)(g >> 2) * 16384 + (g & 3) * 4096;
+            *reinterpret_cast<h16x8*>(o) = hi;
+            *reinterpret_cast<h16x8*>(o + 2048) = lo;
+        }
     }
 }
 

@@ -23,19 +23,17 @@ extern "C" size_t casmtr_dual_softmax_ws_bytes(int B, int L, int S) { return ds_
 extern "C" size_t casmtr_dual_softmax_split_ws_bytes(int B, int L, int S, int C) { return ds_carve(nullptr, nullptr, B, L, S, C); }
 
 template <bool RECIP>
-__global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
-                                                         const uint8_t* __restrict__ mask0,
-                                                         const uint8_t* __restrict__ mask1, float* __restrict__ sim,
-                                                         DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
-                                                         float T, float invT, int NJB, int NIB, const int* __restrict__ guard) {
-    if (guard && *guard == 0) return;   // fallback launch of the split path: runs only when its candidate lists overflowed
+__device__ __forceinline__ void ds_gemm_tile(int bx, int nbx, const float* __restrict__ f0, const float* __restrict__ f1,
+                                             const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
+                                             float* __restrict__ sim, const DsWs& w, int L, int S, int C, float sqrtC,
+                                             float inv_sqrtC, float T, float invT, int NJB, int NIB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33], then epilogue scratch
     float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
     float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
     // Tile order: 8x8 super-tiles (8 A panels + 8 B panels = 2.1 MB, L2-resident), one contiguous run of super-tiles per
     // XCD, so that operand panels are fetched from the fabric once per super-tile instead of once per tile.  Speed only.
     const int NSJ = (NJB + 7) >> 3;
-    const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
+    const int t = xcd_chunk_remap(bx, nbx);
     const int st = t >> 6, wi = t & 63;
     const int tI = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
     if (tI >= NIB || tJ >= NJB) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
@@ -88,6 +86,26 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
     }
     __syncthreads();  // every wave is done reading As/Bs: the region becomes the epilogue's scratch
     ds_tile_epilogue<RECIP, false>(acc, smem, nullptr, nullptr, mask0, mask1, sim, w, b, tI, tJ, L, S, T, invT, NJB, NIB);
+}
+
+// One workgroup per tile.  As the split path's fallback (guard != nullptr; runs only when its candidate lists overflowed) the grid
+// is small and every workgroup walks `ntiles` tiles: the usual case -- flag clear -- is then a few thousand immediate exits.
+template <bool RECIP>
+__global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                         const uint8_t* __restrict__ mask0,
+                                                         const uint8_t* __restrict__ mask1, float* __restrict__ sim,
+                                                         DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
+                                                         float T, float invT, int NJB, int NIB, const int* __restrict__ guard,
+                                                         int ntiles) {
+    if (!guard) {
+        ds_gemm_tile<RECIP>(blockIdx.x, gridDim.x, f0, f1, mask0, mask1, sim, w, L, S, C, sqrtC, inv_sqrtC, T, invT, NJB, NIB);
+        return;
+    }
+    if (*guard == 0) return;
+    for (int bx = blockIdx.x; bx < ntiles; bx += gridDim.x) {
+        ds_gemm_tile<RECIP>(bx, ntiles, f0, f1, mask0, mask1, sim, w, L, S, C, sqrtC, inv_sqrtC, T, invT, NJB, NIB);
+        __syncthreads();   // the epilogue's scratch becomes the next tile's operand buffers
+    }
 }
 
 // combine block partials -> per row/col (max, sum, first argmax); next_conf = softmax value at the argmax = 1/sum.
@@ -375,12 +393,13 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
     {
         ProfScope ps(guard ? -1 : CASMTR_PROF_DS_GEMM, s);
         const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
+        const int gx = guard ? min(ntiles, 768) : ntiles;
         if (recip)
-            hipLaunchKernelGGL(ds_gemm_kernel<true>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
-                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard);
+            hipLaunchKernelGGL(ds_gemm_kernel<true>, dim3(gx, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard, ntiles);
         else
-            hipLaunchKernelGGL(ds_gemm_kernel<false>, dim3(ntiles, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
-                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard);
+            hipLaunchKernelGGL(ds_gemm_kernel<false>, dim3(gx, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard, ntiles);
     }
     CASMTR_CHECK_LAUNCH();
     {
