@@ -7,6 +7,7 @@ The training branch (:264-314, GT window labels, detector heads) is outside the 
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from .cascade_functions import valid_extents
@@ -63,6 +64,8 @@ class CascadeMatching(nn.Module):
         implicit = isinstance(idx_c01, ops.WindowIndex)
         if not implicit:
             idx_c01, idx_c10 = idx_c01.contiguous(), idx_c10.contiguous()
+        if self.post_process.method == "d2d":
+            data["S_d2d"], data["d2d_w"] = self._d2d_scores(f0, hw0), hw0[1] // 4
         d01 = ops.window_match(f0, f1, idx_c01, self.temperature, mask_c0, mask_c1, recip=self.recip, want_conf=True, hw=hw0)
         d10 = ops.window_match(f1, f0, idx_c10, self.temperature, mask_c1, mask_c0, recip=self.recip, want_conf=False, hw=hw1)
         if implicit and self.materialize_idx:
@@ -80,6 +83,22 @@ class CascadeMatching(nn.Module):
         data[f"stage_{level}"].update(**match_result)
         if "m_bids" in match_result:
             data["m_bids"] = match_result["m_bids"]
+
+    @staticmethod
+    def _d2d_scores(feat, hw):
+        """cascade_matching.py:90-104 ('d2d' detection score on the 1/4 sub-grid): channel spread of the normalised feature at every 4th
+        position times the (min-max normalised) norm of its 5 x 5 high-pass response, [B, (h/4)*(w/4), 1].  Plain torch: only the
+        unshipped 'd2d' PostProcess reads it."""
+        B, N, C = feat.shape
+        h, w = hw
+        x = (feat / C ** .5).reshape(B, h, w, C)
+        spread = x[:, ::4, ::4].std(dim=-1).reshape(B, -1, 1)             # nearest-neighbour x0.25 = every 4th row / column
+        xc = x.permute(0, 3, 1, 2)
+        box = F.avg_pool2d(xc, 5, stride=4, padding=2, divisor_override=1)   # 5 x 5 sums, zero padded, at the same positions
+        ctr = xc[:, :, ::4, ::4]
+        resp = ((24.0 + 1.0 / 25.0) * ctr - box / 25.0).norm(dim=1)         # kernel: -1/25 everywhere, 24 at the centre
+        resp = (resp - resp.min()) / (resp.max() - resp.min())
+        return spread * resp.reshape(B, -1, 1)
 
     @classmethod
     def finalize(cls, data, level):
@@ -117,7 +136,7 @@ class CascadeMatching(nn.Module):
         valid = None
         if f"mask_{level}0" in data:
             valid = valid_extents(data[f"mask_{level}0"], data[f"mask_{level}1"])
-        extra = self.post_process.extra_mask(next_conf_c01, hw0)
+        extra = self.post_process.extra_mask(next_conf_c01, hw0, data, next_idx_c01, hw1)
         sel = ops.nms_select(next_conf_c01, next_idx_c01, next_idx_c10, hw0, hw1, nms_window=self.post_process.nms_window,
                              test_thr=float(self.test_thr), pre=pre, border_rm=int(self.border_rm), valid_hw=valid,
                              double_check=bool(self.double_check), extra_keep=extra)

@@ -242,6 +242,78 @@ def local_window_topk_mask(conf, hw, window_size, topk):
     return np.ascontiguousarray(keep.reshape(B, h // ws, w // ws, ws, ws).transpose(0, 1, 3, 2, 4).reshape(B, h * w))
 
 
+def d2d_scores(feat, hw):
+    """CascadeMatching.forward, 'd2d' branch (cascade_matching.py:88-104): S_d2d [B,(h/4)*(w/4),1] from feat_c0 [B,h*w,C].
+    std over channels (unbiased, torch.std) of feat / sqrt(C) at every 4th position (F.interpolate nearest, x0.25) times the channel
+    norm of the depth-wise 5x5 response (kernel -1/25, centre 24, stride 4, zero padding 2), min-max normalised over the whole batch."""
+    feat = _f(feat)
+    B, N, Cc = feat.shape
+    h, w = hw
+    x = (feat / np.float32(Cc ** .5)).reshape(B, h, w, Cc).astype(np.float32)
+    s_as = x[:, ::4, ::4].std(axis=-1, ddof=1, dtype=np.float64).astype(np.float32)
+    xp = np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)))
+    ho, wo = (h + 4 - 5) // 4 + 1, (w + 4 - 5) // 4 + 1
+    resp = np.zeros((B, ho, wo, Cc), np.float64)
+    for dy in range(5):
+        for dx in range(5):
+            kv = 24.0 if (dy, dx) == (2, 2) else -1.0 / 25.0
+            resp += kv * xp[:, dy:dy + 4 * ho:4, dx:dx + 4 * wo:4].astype(np.float64)
+    s_rs = np.sqrt((resp.astype(np.float32).astype(np.float64) ** 2).sum(-1)).astype(np.float32)
+    s_rs = (s_rs - s_rs.min()) / (s_rs.max() - s_rs.min())
+    return (s_as.reshape(B, -1, 1) * s_rs.reshape(B, -1, 1)).astype(np.float32)
+
+
+def d2d_mask(next_conf, s_d2d, hw, window_size):
+    """PostProcess 'd2d' (post_processing.py:122-143) before the threshold: per pair as many positions as the max-pool NMS keeps, taken
+    from the top of S_d2d (sub-grid position (y, x) -> grid position (4y, 4x)).  -> bool [B,h*w]"""
+    next_conf, s = _f(next_conf), _f(s_d2d)
+    B = next_conf.shape[0]
+    h, w = hw
+    z = np.zeros((B, h * w), np.int64)
+    num = nms_select(next_conf, z, z, hw, hw, nms_window=window_size, test_thr=-np.inf, double_check=False)["keep"].sum(1)
+    s = s.reshape(B, -1)
+    dw = w // 4
+    keep = np.zeros((B, h * w), bool)
+    for b in range(B):
+        top = np.argsort(-s[b], kind="stable")[:min(s.shape[1], int(num[b]))]
+        keep[b, (top // dw * 4) * (dw * 4) + top % dw * 4] = True
+    return keep
+
+
+def conv_soft_argmax_mask(next_conf, hw, window_size, stride=1, temperature=1.0):
+    """PostProcess 'softargmax_nms' (post_processing.py:93-110) before the threshold.  PARITY UNPINNED: the method is
+    kornia.geometry.ConvSoftArgmax2d (kornia 0.6.2, kornia/geometry/subpix/spatial_soft_argmax.py: conv_soft_argmax2d with
+    normalized_coordinates=False, eps 1e-8), absent from /root/reference and from this image; restated from the published algorithm:
+      e = exp((x - max x) / T); per window (zero padded): den = sum e + eps; offset = sum(e * g) / den with g the window grid in
+      kornia's normalised units (-1 .. 1 across the window, x then y); position = offset + window centre in pixels (even windows: the
+      mean of the central pixels); the reference rounds it, forms channel0 * w0c + channel1 (:104) and scatters True there."""
+    x = _f(next_conf).astype(np.float64)
+    B = x.shape[0]
+    h, w = hw
+    ws = window_size
+    pad = ws // 2 if stride == 1 else 0
+    x = x.reshape(B, h, w)
+    e = np.exp(((x - x.max(axis=(1, 2), keepdims=True)) / temperature).astype(np.float32)).astype(np.float64)
+    ep = np.pad(e, ((0, 0), (pad, pad), (pad, pad)))
+    gy, gx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    gxp, gyp = np.pad(gx, pad), np.pad(gy, pad)
+    ho, wo = (h + 2 * pad - ws) // stride + 1, (w + 2 * pad - ws) // stride + 1
+    off = np.linspace(-1.0, 1.0, ws) if ws > 1 else np.zeros(1)
+    c1, c2 = (ws // 2, ws // 2 + 1) if ws % 2 else (ws // 2 - 1, ws // 2 + 1)
+    keep = np.zeros((B, h * w), bool)
+    for oy in range(ho):
+        for ox in range(wo):
+            win = ep[:, oy * stride:oy * stride + ws, ox * stride:ox * stride + ws]
+            den = win.sum(axis=(1, 2)) + 1e-8
+            cx = (win * off[None, None, :]).sum(axis=(1, 2)) / den + gxp[oy * stride + c1:oy * stride + c2, ox * stride + c1:ox * stride + c2].mean()
+            cy = (win * off[None, :, None]).sum(axis=(1, 2)) / den + gyp[oy * stride + c1:oy * stride + c2, ox * stride + c1:ox * stride + c2].mean()
+            flat = np.rint(cx.astype(np.float32)).astype(np.int64) * w + np.rint(cy.astype(np.float32)).astype(np.int64)
+            if (flat < 0).any() or (flat >= h * w).any():
+                raise IndexError("softargmax_nms: index out of range (torch.scatter fails in the reference too)")
+            keep[np.arange(B), flat] = True
+    return keep
+
+
 def nms_select(next_conf01, next_idx01, next_idx10, hw0, hw1, nms_window=5, test_thr=0.2, pre=(), border_rm=0,
                valid_hw=None, double_check=True, extra_keep=None):
     """pre: sequence of (pre_conf [B,hp*wp], (hp,wp), pre_thr)."""

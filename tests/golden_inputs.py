@@ -51,6 +51,8 @@ CASES = {
         # §8 f.4: PostProcess 'local_window_nms' (top-k per non-overlapping window), unused by the shipped configs
         "local_window": dict(seed=54, B=2, coarse_hw=(12, 16), C=128, post=dict(method="local_window_nms", window_size=4, topk=2),
                              test_thr=0.05),
+        # §8 f.4: PostProcess 'd2d' (as many positions as the max-pool NMS keeps, from the top of the detector score S_d2d)
+        "d2d": dict(seed=55, B=2, coarse_hw=(12, 16), C=128, post=dict(method="d2d", window_size=5), test_thr=0.05, border_rm=0),
     },
 }
 

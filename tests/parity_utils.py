@@ -68,3 +68,18 @@ def dot_score_fn(fa, fb, mask_a=None, mask_b=None):
 
 def match_set(b, i, j):
     return set(zip(np.asarray(b).tolist(), np.asarray(i).tolist(), np.asarray(j).tolist()))
+
+
+def post_extra_mask(post, next_conf_c01, feat0, hw):
+    """the oracle's restatement of the PostProcess methods that reach the selection as an extra keep mask:
+    'local_window_nms' (post_processing.py:76-93), 'd2d' (:122-143 + cascade_matching.py:88-104), 'softargmax_nms' (:93-110)"""
+    import oracle
+    if not post or post["method"] in (None, "maxpool_nms"):
+        return None
+    if post["method"] == "local_window_nms":
+        return oracle.local_window_topk_mask(next_conf_c01, hw, post["window_size"], post["topk"])
+    if post["method"] == "d2d":
+        return oracle.d2d_mask(next_conf_c01, oracle.d2d_scores(feat0, hw), hw, post["window_size"])
+    if post["method"] == "softargmax_nms":
+        return oracle.conv_soft_argmax_mask(next_conf_c01, hw, post["window_size"], post.get("stride", 1), post.get("temperature", 1.0))
+    raise KeyError(post["method"])

@@ -9,7 +9,7 @@ import torch
 
 import oracle
 from golden_inputs import CASES, make_inputs
-from parity_utils import assert_close, audit_index_mismatches, dot_score_fn, load_golden, match_set
+from parity_utils import assert_close, audit_index_mismatches, dot_score_fn, load_golden, match_set, post_extra_mask
 
 pytestmark = pytest.mark.gpu
 SOFTMAX_TOL = 1e-4
@@ -316,8 +316,8 @@ def test_window_match_and_select(ops, name, recip):
     assert_close(N(dg["conf_matrix"]), og["conf_matrix"], SOFTMAX_TOL, "generic conf")
     # selection: fed with the reference's own stage outputs it is pure comparison logic -> exact vs the fixture
     post, extra = cfg.get("post"), None
-    if post:   # 'local_window_nms': the survivors arrive as an extra keep mask (here: the oracle's restatement of post_processing.py:76-93)
-        extra = T(oracle.local_window_topk_mask(g["next_conf_c01"], (h, w), post["window_size"], post["topk"]).astype(np.uint8))
+    if post:   # 'local_window_nms' / 'd2d': the survivors arrive as an extra keep mask (here: the oracle's restatement of the method)
+        extra = T(post_extra_mask(post, g["next_conf_c01"], inp["feat0"], (h, w)).astype(np.uint8))
     sel = ops.nms_select(T(g["next_conf_c01"]), T(g["next_idx_c01"].astype(np.int64)), T(g["next_idx_c10"].astype(np.int64)),
                          (h, w), (h, w), nms_window=5 if (cfg.get("nms", True) and not post) else 0, test_thr=cfg.get("test_thr", 0.2),
                          pre=[(T(inp["pre_conf"]), (hc, wc), cfg.get("pre_thr", 0.2))], border_rm=cfg.get("border_rm", 2),

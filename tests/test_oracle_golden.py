@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from golden_inputs import CASES, checksum, make_inputs
-from parity_utils import assert_close, audit_index_mismatches, dot_score_fn, load_golden, match_set
+from parity_utils import assert_close, audit_index_mismatches, dot_score_fn, load_golden, match_set, post_extra_mask
 
 F32_SUM_TOL = 5e-5      # different fp32 summation order (torch.sum / einsum vs fmaf chain)
 SOFTMAX_TOL = 1e-4      # north_star: softmax scores within 1e-4 fp32
@@ -206,8 +206,8 @@ def test_cascade_matching(name):
     audit_index_mismatches(d01["next_idx"], g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], mq, mk), "cascade next_idx_c01")
     audit_index_mismatches(d10["next_idx"], g["next_idx_c10"], dot_score_fn(inp["feat1"], inp["feat0"], mk, mq), "cascade next_idx_c10")
     post, extra = cfg.get("post"), None
-    if post:   # PostProcess 'local_window_nms' (post_processing.py:76-93), restated in oracle.local_window_topk_mask
-        extra = oracle.local_window_topk_mask(g["next_conf_c01"], (h, w), post["window_size"], post["topk"])
+    if post:   # PostProcess 'local_window_nms' / 'd2d' (post_processing.py:76-93, :122-143), restated in the oracle
+        extra = post_extra_mask(post, g["next_conf_c01"], inp["feat0"], (h, w))
     sel = oracle.nms_select(g["next_conf_c01"], g["next_idx_c01"].astype(np.int64), g["next_idx_c10"].astype(np.int64),
                             (h, w), (h, w), nms_window=5 if (cfg.get("nms", True) and not post) else 0, extra_keep=extra,
                             test_thr=cfg.get("test_thr", 0.2), pre=[(inp["pre_conf"], (hc, wc), cfg.get("pre_thr", 0.2))],
