@@ -114,14 +114,14 @@ int ds_split_launch(const float* feat0, const float* feat1, const DsWs& w, int B
 }
 
 // =================================================================================================== GEMM
-// 4 KB = 4 lane-linear LDS-DMA instructions behind one M0 write: the immediate offset advances the LDS destination and the
-// source address together (tools/probes/glds_offset.hip).  M0 is not restored: nothing else in this kernel uses it.
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {   // pins a wave-uniform address to an SGPR pair
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
 }
+// 4 KB = 4 lane-linear LDS-DMA instructions behind one M0 write: the immediate offset advances the LDS destination and the
+// source address together (tools/probes/glds_offset.hip).  M0 is not restored: nothing else in this kernel uses it.
 __device__ __forceinline__ void glds_4k(const char* base, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %0, %1\n\t"
@@ -138,15 +138,140 @@ __device__ __forceinline__ void glds_2k(const char* base, unsigned voff, unsigne
                  :: "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
+// Epilogue of an interior tile (all 128 rows and 128 columns in range), straight from the accumulator registers (32x32 MFMA
+// C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Same results as ds_tile_epilogue<true, true>
+// (ds_common.hpp, which edge tiles still use) with the per-element overhead removed: one uniform tile pointer + a 32-bit lane
+// offset + a scalar row offset per store instead of 64-bit address arithmetic, no bounds predication, padding masks from the
+// SIGN of the staged factors (facA / facB negative = masked row / column) instead of byte loads, ds_read_b128 transposes.
+//   scratch: 4 x [32][68] wave-private slabs, then rowx[2][128][2], colx[2][128][2]
+#define DS16_WL 68
+template <bool MASKED>
+__device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* scratch, const float* facA, const float* facB,
+                                                  float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ, int L, int S,
+                                                  int NJB, int NIB) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    const int hi = lane >> 5, ln = lane & 31;
+    float* wl = scratch + wave * (32 * DS16_WL);
+    float* rowx = scratch + 4 * 32 * DS16_WL;           // [2 wc][128 rows][2]
+    float* colx = rowx + 2 * 128 * 2;                   // [2 wr][128 cols][2]
+    // addresses: wave-uniform base (SGPR pair) + 32-bit byte offset (lane part + scalar row part): no 64-bit VALU arithmetic
+    char* tile = const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(sim + ((size_t)b * L + tI * DS_BM + wr * 64) * S + tJ * DS_BN + wc * 64)));
+    char* grp = const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(w.cg_m + (((size_t)b * NIB + tI) * 8 + wr * 4) * S + tJ * DS_BN + wc * 64)));
+    const unsigned lane_off = (unsigned)(4 * hi * S + ln) * 4u, grp_off = (unsigned)(hi * S + ln) * 4u;
+    const unsigned row_bytes = (unsigned)S * 4u;
+    float fbv[2];
+    bool cmask[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const float f = facB[wc * 64 + tj * 32 + ln];
+        fbv[tj] = __builtin_fabsf(f);
+        cmask[tj] = MASKED && __float_as_int(f) < 0;
+    }
+    // ---- 1. scale, mask, store; 2. column statistics on the fly.  Stores: SGPR row base + constant lane offset (no VALU address
+    //         arithmetic).  (A slab-at-a-time variant fits 128 VGPRs = 4 workgroups per CU, but measured no faster than this one
+    //         at 3: 1.74 / 1.91 ms unmasked / masked against 1.74 / 1.79.)
+    float xv[2][2][16];
+    float cmax[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const f32x4 f4[4] = {*reinterpret_cast<const f32x4*>(facA + wr * 64 + ti * 32 + 4 * hi),
+                             *reinterpret_cast<const f32x4*>(facA + wr * 64 + ti * 32 + 8 + 4 * hi),
+                             *reinterpret_cast<const f32x4*>(facA + wr * 64 + ti * 32 + 16 + 4 * hi),
+                             *reinterpret_cast<const f32x4*>(facA + wr * 64 + ti * 32 + 24 + 4 * hi)};   // rows (q, 0..3)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            float g16 = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = f4[r >> 2][r & 3];
+                float x = __fmul_rn(__fmul_rn(acc[ti][tj][r], __builtin_fabsf(f)), fbv[tj]);
+                if (MASKED && (__float_as_int(f) < 0 || cmask[tj])) x = NEG_FILL;
+                const char* rowbase = tile + (size_t)(ti * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;    // wave-uniform
+                if (tj == 0) asm volatile("global_store_dword %0, %1, %2" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
+                else asm volatile("global_store_dword %0, %1, %2 offset:128" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
+                xv[ti][tj][r] = x;
+                g16 = fmaxf(g16, x);
+            }
+            // maximum of this lane's 16-row group (wr, ti, hi): the sparse pass 2 reads 16 rows of a column, not 128
+            const char* gb = grp + (size_t)(ti * 2) * row_bytes;
+            if (tj == 0) asm volatile("global_store_dword %0, %1, %2" :: "v"(grp_off), "v"(g16), "s"(gb) : "memory");
+            else asm volatile("global_store_dword %0, %1, %2 offset:128" :: "v"(grp_off), "v"(g16), "s"(gb) : "memory");
+            cmax[tj] = fmaxf(cmax[tj], g16);
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const float m = fmaxf(cmax[tj], __shfl_xor(cmax[tj], 32));
+        float sm = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += __expf(xv[ti][tj][r] - m);
+        sm += __shfl_xor(sm, 32);
+        if (hi == 0) {
+            float* o = colx + (wr * 128 + wc * 64 + tj * 32 + ln) * 2;
+            o[0] = m; o[1] = sm;
+        }
+    }
+    // ---- 3. rows: 32-row slabs through the wave-private LDS region, lane <-> (row ln, column half hi)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) wl[((r & 3) + 8 * (r >> 2) + 4 * hi) * DS16_WL + tj * 32 + ln] = xv[ti][tj][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const f32x4* rp = reinterpret_cast<const f32x4*>(wl + ln * DS16_WL + hi * 32);
+        f32x4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = rp[c];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m = fmaxf(fmaxf(m, fmaxf(v[c].x, v[c].y)), fmaxf(v[c].z, v[c].w));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sm += (__expf(v[c].x - m) + __expf(v[c].y - m)) + (__expf(v[c].z - m) + __expf(v[c].w - m));
+        sm += __shfl_xor(sm, 32);
+        if (hi == 0) {
+            float* o = rowx + (wc * 128 + wr * 64 + ti * 32 + ln) * 2;
+            o[0] = m; o[1] = sm;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    // ---- 4. combine the two waves that share a row (wc = 0,1) / a column (wr = 0,1)
+    {
+        const float* x0 = (tid < 128 ? rowx : colx) + (tid & 127) * 2;
+        const float* x1 = x0 + 128 * 2;
+        const float ma = x0[0], mb = x1[0];
+        const float mm = fmaxf(ma, mb);
+        const float tot = x0[1] * __expf(ma - mm) + x1[1] * __expf(mb - mm);
+        if (tid < 128) {
+            const size_t o = ((size_t)b * NJB + tJ) * L + tI * DS_BM + tid;
+            w.rp_m[o] = mm; w.rp_s[o] = tot;
+        } else {
+            const size_t o = ((size_t)b * NIB + tI) * S + tJ * DS_BN + tid - 128;
+            w.cp_m[o] = mm; w.cp_s[o] = tot;
+        }
+    }
+}
+
 // 128 x 128 block tile, 4 waves x (64 x 64), k-stages of 16 (8 KB of A image + 8 KB of B image = half a 16 KB image chunk),
-// double buffered: the DMA of stage ks+1 is in flight while stage ks feeds 12 MFMAs per wave.  40 KB of LDS -> 4 workgroups
-// per CU, 4 waves per SIMD: other workgroups' MFMA loops run under a workgroup's epilogue (VALU / LDS / stores).
+// double buffered: the DMA of stage ks+1 is in flight while stage ks feeds 12 MFMAs per wave.  40 KB of LDS, <= 170 VGPRs -> 3
+// workgroups per CU: other workgroups' MFMA loops run under a workgroup's epilogue (VALU / LDS / stores).
 #define DS16_STAGE 16384
-#define DS16_LDS (4 * 32 * 65 * 4 + 2 * 2 * 128 * 3 * 4 + 2 * 128 * 4)   // epilogue scratch (aliases the stages) + factors
-__global__ __launch_bounds__(256, 4) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
+#define DS16_LDS (4 * 32 * 65 * 4 + 2 * 2 * 128 * 3 * 4 + 2 * 128 * 4)   // epilogue scratch (aliases the stages; the interior-tile
+                                                                          // layout 4*32*68 + 2*2*128*2 floats is 512 B smaller) + factors
+__global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
-                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB, int dbg) {
+                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
     char* lds = reinterpret_cast<char*>(smem);
     float* facA = smem + (DS16_LDS - 2 * 128 * 4) / 4;
@@ -159,8 +284,19 @@ __global__ __launch_bounds__(256, 4) void ds_gemm16_kernel(const _Float16* __res
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
-    if (tid < 128) facA[tid] = fa[((size_t)b * NIB + tI) * 128 + tid];
-    else facB[tid - 128] = fb[((size_t)b * NJB + tJ) * 128 + tid - 128];
+    // factors of the tile's rows / columns; negative = the row / column is masked (padding), see ds_split_epilogue
+    bool masked = false;
+    if (tid < 128) {
+        const int gi = tI * DS_BM + tid;
+        const float f = fa[((size_t)b * NIB + tI) * 128 + tid];
+        masked = mask0 && gi < L && mask0[(size_t)b * L + gi] == 0;
+        facA[tid] = masked ? -f : f;
+    } else {
+        const int gj = tJ * DS_BN + tid - 128;
+        const float f = fb[((size_t)b * NJB + tJ) * 128 + tid - 128];
+        masked = mask0 && gj < S && mask1[(size_t)b * S + gj] == 0;
+        facB[tid - 128] = masked ? -f : f;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -172,7 +308,7 @@ __global__ __launch_bounds__(256, 4) void ds_gemm16_kernel(const _Float16* __res
     const char* b_src = uniform_ptr(reinterpret_cast<const char*>(imgB) + ((size_t)b * NJB + tJ) * (size_t)KS * 8192);
     const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_byte_addr(lds) + (unsigned)(wave * 2048)));
-    __syncthreads();   // the factor loads above have completed (compiler-counted) before any DMA is outstanding
+    const int any_masked = __syncthreads_or(masked);   // (barrier: the factor loads above have completed before any DMA is outstanding)
     glds_2k(a_src, voff, lds0);
     glds_2k(b_src, voff, lds0 + 8192);
     const int hi = lane >> 5, ln = lane & 31;
@@ -212,8 +348,15 @@ __global__ __launch_bounds__(256, 4) void ds_gemm16_kernel(const _Float16* __res
             for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
-    if (dbg & 1) { if (acc[0][0][0] == 123.456f) sim[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
-    ds_tile_epilogue<true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
+    if (tI * DS_BM + DS_BM <= L && tJ * DS_BN + DS_BN <= S) {
+        if (any_masked) ds_split_epilogue<true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+        else ds_split_epilogue<false>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+    } else {   // edge tile: the general epilogue (bounds predication, masks from memory)
+        if (tid < 128) facA[tid] = __builtin_fabsf(facA[tid]);
+        else facB[tid - 128] = __builtin_fabsf(facB[tid - 128]);
+        __syncthreads();
+        ds_tile_epilogue<true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
+    }
 }
 
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s) {
@@ -222,7 +365,7 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
     hipLaunchKernelGGL(ds_gemm16_kernel, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
-                       C / 16, NJB, NIB, getenv("DS16_DBG") ? atoi(getenv("DS16_DBG")) : 0);
+                       C / 16, NJB, NIB);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -238,13 +381,12 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
 // segment, which also feeds the column-best atomics.  Same candidate lists and best-of-row / best-of-column keys as the dense pass.
 #define DS_SP_CHUNK 8
 __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict__ sim, DsWs w, int B, int L, int S, int NJB, int NIB,
-                                                        float thr, int dbg) {
+                                                        float thr) {
     const int lane = threadIdx.x & 63;
     const int gw0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int RG = (L + 63) / 64, CG = (S + 63) / 64;
     const int RCH = (NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK, CCH = (NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK;   // block chunks per wave
     if (gw0 < B * RG * RCH) {
-        if (dbg & 1) return;
         const int gw = gw0 / RCH, t0 = (gw0 % RCH) * DS_SP_CHUNK;
         const int b = gw / RG, g = gw % RG, i = g * 64 + lane;
         const bool ok = i < L;
@@ -261,7 +403,6 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
             const int tJ = t0 + k;
             const float m = mv[k];
             unsigned long long bal = __ballot(ok && tJ < NJB && m >= lim && m != NEG_FILL);
-            if (dbg & 4) bal = 0;
             while (bal) {
                 const int l = __ffsll((long long)bal) - 1;
                 bal &= bal - 1;
@@ -296,7 +437,6 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
         }
     } else if (gw0 < B * RG * RCH + B * CG * CCH) {
         const int gc0 = gw0 - B * RG * RCH;
-        if (dbg & 2) return;
         const int gc = gc0 / CCH, t0 = (gc0 % CCH) * DS_SP_CHUNK;
         const int b = gc / CG, g = gc % CG, j = g * 64 + lane;
         const bool ok = j < S;
@@ -335,7 +475,7 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
 int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const int waves = B * ((L + 63) / 64) * ((NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK) + B * ((S + 63) / 64) * ((NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK);
-    hipLaunchKernelGGL(ds_sparse_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, sim, w, B, L, S, NJB, NIB, thr, getenv("DS_SP_DBG") ? atoi(getenv("DS_SP_DBG")) : 0);
+    hipLaunchKernelGGL(ds_sparse_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, sim, w, B, L, S, NJB, NIB, thr);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
