@@ -29,6 +29,7 @@ struct DsWs {  // carve of stats_ws
     int* blk;                        // compaction block counts
     float *na, *nb;                  // [B][Lp], [B][Sp] |row| / sqrt(C), rounded up
     float *fa, *fb;                  // [B][Lp], [B][Sp] epilogue factors (2^e / (C T), 2^e)
+    int *exA, *exB;                  // [B][Lp], [B][Sp] normalisation exponents e
     float *rthr, *cthr;              // [B*L], [B*S] candidate thresholds
     float* cg_m;                     // [B][NIB][8][S] column maxima of the 16-row groups (wr, ti, hi) of each 128-row block
     int *rcand, *ccand;              // [B*L][CAP], [B*S][CAP]
@@ -62,6 +63,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
     if (C > 0) {
         CARVE(na, float, (size_t)B * Lp); CARVE(nb, float, (size_t)B * Sp);
         CARVE(fa, float, (size_t)B * Lp); CARVE(fb, float, (size_t)B * Sp);
+        CARVE(exA, int, (size_t)B * Lp); CARVE(exB, int, (size_t)B * Sp);
         CARVE(rthr, float, (size_t)B * L); CARVE(cthr, float, (size_t)B * S);
         CARVE(cg_m, float, (size_t)B * NIB * 8 * S);
         CARVE(rcand, int, (size_t)B * L * DS_CAND_CAP); CARVE(ccand, int, (size_t)B * S * DS_CAND_CAP);

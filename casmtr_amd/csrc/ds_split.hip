@@ -23,81 +23,80 @@
 namespace casmtr {
 
 // =================================================================================================== operand images
-// One workgroup per 128-row block.  Phase 1 (wave per row, coalesced 1 KB reads): row maximum -> exponent, row norm.
-// Phase 2 (lane <-> row, 32 B of a row per lane and step, L2-warm): normalise, split, write the tile image
+// Pass 1 (ds_rownorm_kernel, wave per row, coalesced 1 KB reads): row maximum -> exponent, row norm.
+// Pass 2 (ds_split_kernel, lane <-> row, 32 B of a row per lane and step): normalise, split, write the tile image
 //   img[b][rb][ks = c/32][kg = (c/8)%4][part hi/lo][row 128][8 f16]   -- 16 KB per (row block, k-stage), every 1 KB of it one
 // wave-instruction of the GEMM's LDS-DMA and, inside a kg plane, the lane-linear 16-B runs its ds_read_b128 fragment loads want.
-__global__ __launch_bounds__(256) void ds_split_kernel(const float* __restrict__ f, int N, int C, float inv_sqrtC,
-                                                       float k0, _Float16* __restrict__ img, float* __restrict__ fac,
-                                                       float* __restrict__ nrm, unsigned* __restrict__ nmax, int NRB) {
-    __shared__ int ex[128];
-    const int rb = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Np = NRB * 128;
-    float wmax = 0.f;
-    // 8 rows per step: their loads are all in flight before the first reduction (a row at a time is one exposed HBM round
-    // trip per row, 32 in a row per wave)
-    for (int rr0 = 0; rr0 < 32; rr0 += 8) {
-        float mx[8], ss[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int gi = rb * 128 + wave * 32 + rr0 + q;
-            mx[q] = 0.f; ss[q] = 0.f;
-            if (gi < N) {
-                const float* p = f + ((size_t)b * N + gi) * C;
-                for (int c = lane * 4; c < C; c += 256) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
-                    mx[q] = fmaxf(fmaxf(mx[q], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-                    ss[q] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = wave * 32 + rr0 + q, gi = rb * 128 + r;
-            const float m = wave_max_f32(mx[q]);
-            const float s2 = wave_sum_f32(ss[q]);
-            // largest element -> [512, 1024): products < 2^20, 256-term sums < 2^28, f16 hi parts far from 65504
-            const int e = (m > 0.f && m < INFINITY) ? ilogbf(m) - 9 : 0;
-            // |a| / sqrt(C), rounded up: 1.001 covers the fp32 summation (<= C 2^-24 relative) and the square root
-            const float nr = sqrtf(s2) * inv_sqrtC * 1.001f;
-            if (lane == 0) {
-                ex[r] = e;
-                fac[(size_t)b * Np + gi] = gi < N ? ldexpf(k0, e) : 0.f;
-                nrm[(size_t)b * Np + gi] = gi < N ? nr : 0.f;
-            }
-            if (gi < N) wmax = fmaxf(wmax, nr);
+// (1) one wave per row: exponent of the row maximum, epilogue factor, row norm, batch maximum of the norms
+__global__ __launch_bounds__(256) void ds_rownorm_kernel(const float* __restrict__ f, int N, int C, float inv_sqrtC, float k0,
+                                                         int* __restrict__ ex, float* __restrict__ fac, float* __restrict__ nrm, int Np) {
+    const int lane = threadIdx.x & 63;
+    const int gi = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;   // row of the padded range [0, Np)
+    if (gi >= Np) return;
+    float mx = 0.f, ss = 0.f;
+    if (gi < N) {
+        const float* p = f + ((size_t)b * N + gi) * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
     }
-    if (lane == 0 && wmax > 0.f) atomicMax(nmax + b, __float_as_uint(wmax));
+    mx = wave_max_f32(mx);
+    ss = wave_sum_f32(ss);
+    // largest element -> [512, 1024): products < 2^20, 256-term sums < 2^28, f16 hi parts far from 65504
+    const int e = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
+    // |a| / sqrt(C), rounded up: 1.001 covers the fp32 summation (<= C 2^-24 relative) and the square root
+    const float nr = gi < N ? sqrtf(ss) * inv_sqrtC * 1.001f : 0.f;
+    if (lane == 0) {
+        ex[(size_t)b * Np + gi] = e;
+        fac[(size_t)b * Np + gi] = gi < N ? ldexpf(k0, e) : 0.f;
+        nrm[(size_t)b * Np + gi] = nr;
+    }
+}
+
+// (1b) workgroup per (pair, side): maximum of the row norms (86 k same-address atomicMax from pass 1 would serialise: 2 ms)
+__global__ __launch_bounds__(256) void ds_nmax_kernel(const float* __restrict__ na, const float* __restrict__ nb, int NpA, int NpB,
+                                                      unsigned* __restrict__ namax, unsigned* __restrict__ nbmax) {
+    __shared__ float wm[4];
+    const int b = blockIdx.x, side = blockIdx.y, Np = side ? NpB : NpA;
+    const float* p = (side ? nb : na) + (size_t)b * Np;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Np; i += 256) m = fmaxf(m, p[i]);
+    m = wave_max_f32(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    const int r = tid & 127, gi = rb * 128 + r, e = ex[r];
-    const float* p = f + ((size_t)b * N + (gi < N ? gi : N - 1)) * C;
-    char* out = reinterpret_cast<char*>(img) + ((size_t)b * NRB + rb) * (size_t)(C / 32) * 16384 + r * 16;
-    for (int g0 = tid >> 7; g0 < C / 8; g0 += 8) {   // 4 k-groups per step: 8 loads in flight
-        f32x4 v[4][2];
+    if (threadIdx.x == 0) (side ? nbmax : namax)[b] = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+}
+
+// (2) wave = 64 rows x one k-stage (32 channels = one 128-B line per row): coalesced reads (8 lanes share a row), transposition
+//     through a wave-private LDS slab to lane <-> row, then normalise, split and write 1 KB runs of the tile image
+__global__ __launch_bounds__(256) void ds_split_kernel(const float* __restrict__ f, int N, int C, const int* __restrict__ ex,
+                                                       _Float16* __restrict__ img, int NRB) {
+    __shared__ float slabs[4 * CASMTR_SLAB_FLOATS];
+    const int rb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ks = blockIdx.z * 2 + (wave >> 1), r0 = (wave & 1) * 64;
+    if (ks >= C / 32) return;
+    const float* base = f + (size_t)b * N * C + ks * 32;
+    f32x4 x[8];
+    wave_rows32_to_lanes(slabs + wave * CASMTR_SLAB_FLOATS, lane,
+                         [&](int rr) { const int gi = rb * 128 + r0 + rr; return base + (size_t)(gi < N ? gi : N - 1) * C; }, x);
+    const int gi = rb * 128 + r0 + lane;
+    const int e = ex[(size_t)b * NRB * 128 + gi];
+    char* out = reinterpret_cast<char*>(img) + (((size_t)b * NRB + rb) * (size_t)(C / 32) + ks) * 16384 + (r0 + lane) * 16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = min(g0 + 2 * q, C / 8 - 1);
-            v[q][0] = *reinterpret_cast<const f32x4*>(p + 8 * g);
-            v[q][1] = *reinterpret_cast<const f32x4*>(p + 8 * g + 4);
+    for (int kg = 0; kg < 4; ++kg) {
+        h16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xn = gi < N ? ldexpf(x[2 * kg + (c >> 2)][c & 3], -e) : 0.f;
+            const _Float16 h = (_Float16)xn;
+            hi[c] = h;
+            lo[c] = (_Float16)(xn - (float)h);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = g0 + 2 * q;
-            if (g >= C / 8) break;
-            const float x[8] = {v[q][0].x, v[q][0].y, v[q][0].z, v[q][0].w, v[q][1].x, v[q][1].y, v[q][1].z, v[q][1].w};
-            h16x8 hi, lo;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float xn = gi < N ? ldexpf(x[c], -e) : 0.f;
-                const _Float16 h = (_Float16)xn;
-                hi[c] = h;
-                lo[c] = (_Float16)(xn - (float)h);
-            }
-            char* o = out + (size_t)(g >> 2) * 16384 + (g & 3) * 4096;
-            *reinterpret_cast<h16x8*>(o) = hi;
-            *reinterpret_cast<h16x8*>(o + 2048) = lo;
-        }
+        *reinterpret_cast<h16x8*>(out + kg * 4096) = hi;
+        *reinterpret_cast<h16x8*>(out + kg * 4096 + 2048) = lo;
     }
 }
 
@@ -107,8 +106,11 @@ int ds_split_launch(const float* feat0, const float* feat1, const DsWs& w, int B
     const float sqrtC = (float)sqrt((double)C);
     const float k0 = (float)(1.0 / ((double)C * (double)temperature));
     (void)recip;   // the operand pre-scaling mode only matters to the exact chain (ds_fix_kernel)
-    hipLaunchKernelGGL(ds_split_kernel, dim3(NIB, B), dim3(256), 0, s, feat0, L, C, 1.0f / sqrtC, k0, w.imgA, w.fa, w.na, w.namax, NIB);
-    hipLaunchKernelGGL(ds_split_kernel, dim3(NJB, B), dim3(256), 0, s, feat1, S, C, 1.0f / sqrtC, 1.0f, w.imgB, w.fb, w.nb, w.nbmax, NJB);
+    hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NIB * 32, B), dim3(256), 0, s, feat0, L, C, 1.0f / sqrtC, k0, w.exA, w.fa, w.na, NIB * 128);
+    hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NJB * 32, B), dim3(256), 0, s, feat1, S, C, 1.0f / sqrtC, 1.0f, w.exB, w.fb, w.nb, NJB * 128);
+    hipLaunchKernelGGL(ds_nmax_kernel, dim3(B, 2), dim3(256), 0, s, w.na, w.nb, NIB * 128, NJB * 128, w.namax, w.nbmax);
+    hipLaunchKernelGGL(ds_split_kernel, dim3(NIB, B, (C + 63) / 64), dim3(256), 0, s, feat0, L, C, w.exA, w.imgA, NIB);
+    hipLaunchKernelGGL(ds_split_kernel, dim3(NJB, B, (C + 63) / 64), dim3(256), 0, s, feat1, S, C, w.exB, w.imgB, NJB);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
