@@ -18,7 +18,9 @@ BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_k
               ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
               ("cascade_quad_kernel", "quad_attn_kernel<cascade>"),
               ("coarse_fused_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
-              ("ds_gemm_kernel", "ds_gemm_kernel"), ("ds_conf_kernel", "ds_conf_kernel"),
+              ("ds_gemm16_kernel", "ds_gemm_kernel"), ("ds_gemm_kernel<", "ds_gemm_kernel[exact fp32; in split mode: the guarded fallback launch]"),
+              ("ds_sparse_kernel", "ds_conf_kernel"), ("ds_conf_kernel", "ds_conf_kernel[dense]"),
+              ("ds_split_kernel", "ds_split_kernel"), ("ds_rownorm_kernel", "ds_split_kernel"), ("ds_fix_kernel", "ds_fix_kernel"),
               ("nchw_to_tokens_kernel", "nchw_to_tokens_kernel"), ("coarse_row_kernel", "coarse_row_kernel"),
               ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel"),
               ("linear_nt_kernel", "linear_nt_kernel"), ("token_pool_kernel", "token_pool_kernel")]
