@@ -24,14 +24,18 @@ struct QuadLayoutBatch {
 __global__ __launch_bounds__(256) void nchw_to_quads_kernel(const QuadLayoutBatch lb) {
     constexpr int RS = 32 * 65 + 2;
     __shared__ float t[2 * RS];
+    // XCD-contiguous tile order: neighbouring tiles (next 64 pixels of the same image rows, next quad row) share the cache lines their
+    // 256-byte segments straddle (rows are 416 / 832 B, not line multiples); round-robin placement made every XCD fetch those lines
+    // for itself: FETCH_SIZE 1.5x the input bytes (profiles/r03e_pmc_fetch_size.csv)
+    const int bid = xcd_chunk_remap(blockIdx.x, gridDim.x);
     int ti = 0;
 #pragma unroll
     for (int i = 1; i < CASMTR_MAX_QLAYOUT; ++i)
-        if (i < lb.n && (int)blockIdx.x >= lb.tile_begin[i]) ti = i;
+        if (i < lb.n && bid >= lb.tile_begin[i]) ti = i;
     const int C = lb.C[ti], h = lb.h[ti], w = lb.w[ti], H = C >> 5, hq = h >> 1, wq = w >> 1, xt_n = (wq + 31) >> 5;
     const float* __restrict__ x = lb.src[ti];
     float* __restrict__ out = lb.dst[ti];
-    int local = blockIdx.x - lb.tile_begin[ti];
+    int local = bid - lb.tile_begin[ti];
     if (lb.tokens[ti]) {
         // [B,C,HW] -> [B,HW,C]: 64 channels x 64 pixels through the same LDS region (the tile of casmtr_nchw_to_tokens, qta_fused.hip)
         float (*tt)[65] = reinterpret_cast<float (*)[65]>(t);
