@@ -7,7 +7,7 @@
 
 using namespace casmtr;
 
-#define CASMTR_MAX_QLAYOUT 9
+#define CASMTR_MAX_QLAYOUT 18   // q, k, v x 3 pyramid levels x the two directions of a layer
 struct QuadLayoutBatch {
     const float* src[CASMTR_MAX_QLAYOUT];
     float* dst[CASMTR_MAX_QLAYOUT];

@@ -219,6 +219,41 @@ class QTAttB(nn.Module):
         self._last_levels = per_level if want_topk else None
         return acc
 
+    def forward_multi(self, calls):
+        """calls: list of (queries, keys, values) pyramid triples of identical shapes whose results do not depend on each other -- the two
+        directions of a transformer layer (transformer.py:295-300: `layer(feat0, feat1), layer(feat1, feat0)` are computed from the same
+        inputs; the 'self' layers likewise).  One layout launch writes all of them into doubled-batch operands and every level kernel
+        runs once -> list of messages, equal to [self.forward(*c) for c in calls]."""
+        n = len(calls[0][0])
+        hw_q = [tuple(q.shape[2:]) for q in reversed(calls[0][0])]
+        hw_k = [tuple(k.shape[2:]) for k in reversed(calls[0][1])]
+        flat = [[t for lvl in zip(reversed(qs), reversed(ks), reversed(vs)) for t in lvl] for qs, ks, vs in calls]
+        same = all(tuple(a.shape) == tuple(b.shape) for f in flat[1:] for a, b in zip(flat[0], f))
+        if (len(calls) < 2 or self.lepe or not same or not self._quad_major_ok(hw_q, hw_k) or any(ops._is_channels_last(t) for f in flat for t in f)
+                or _needs_autograd(self.weight, *[t for f in flat for t in f])):
+            return [self.forward(*c) for c in calls]
+        B = flat[0][0].shape[0]
+        groups = [[f[j].float() for f in flat] for j in range(3 * n)]
+        laid = ops.nchw_to_quads_grouped(groups, [j < 3 for j in range(3 * n)])
+        acc = self._run_levels_quad(laid[:3], laid[3:], hw_q, hw_k, False)
+        return [acc[g * B:(g + 1) * B] for g in range(len(calls))]
+
+    def _run_levels_quad(self, coarse, quads, hw_q, hw_k, want_topk):
+        n = len(hw_q)
+        weight = self._level_weights()
+        out = ops.qta_coarse_level(*coarse, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True)
+        acc, tab = out["acc"], out["topk_tab"]
+        per_level = [out]
+        for i in range(1, n):
+            q, k, v = quads[3 * (i - 1):3 * i]
+            topk = self.topks[i] if i < n - 1 else 0   # the reference computes top-k at the finest level too and discards it
+            out = ops.qta_fine_level_quad(q, k, v, tab, hw_q[i], hw_k[i], self.nhead, topk, w_level=weight[i], acc_in=acc,
+                                          want_message=False, want_topk=want_topk)
+            acc, tab = out["acc"], out["topk_tab"]
+            per_level.append(out)
+        self._last_levels = per_level if want_topk else None
+        return acc
+
     def fused_levels_with_topk(self, levels, hw_q, hw_k):
         """Measurement / test hook: the fused path on `levels` = [(q,k,v)] of [B,C,h,w] tensors, COARSEST first, with the per-level
         top-k tensors the reference keeps internal (:219-227) materialised -> list of per-level dicts (topk_idx, topk_score, acc, ...),
@@ -419,6 +454,25 @@ class CascadeQTAttB(nn.Module):
             return ops.cascade_attn_quad(qm[0], qm[1], qm[2], topk_pos.contiguous(), hw_q, hw_k, self.nhead, rp), None
         q, k, v = ops.nchw_to_tokens_multi([t.float() for t in (query, key, value)])
         return self.forward_tokens(q, k, v, hw_q, hw_k, topk_pos, rel_pos, want_idx)
+
+    def forward_multi(self, calls):
+        """calls: list of (query, key, value, topk_pos) of identical shapes, independent of each other (the two directions of a cascade
+        cross layer, transformer.py:549), no rel_pos, no index output: one layout launch, one attention launch on the doubled batch ->
+        list of messages."""
+        q0, k0 = calls[0][0], calls[0][1]
+        hw_q, hw_k = tuple(q0.shape[2:]), tuple(k0.shape[2:])
+        import os
+        ok = (len(calls) > 1 and os.environ.get("CASMTR_CASCADE_KERNEL", "qm") == "qm"
+              and ops.cascade_quad_supported(self.nhead, self.dim, hw_q, hw_k, calls[0][3].shape[2], self.dilated)
+              and all(tuple(c[j].shape) == tuple(calls[0][j].shape) for c in calls for j in range(4))
+              and not any(ops._is_channels_last(t) for c in calls for t in c[:3]) and not _needs_autograd(*[t for c in calls for t in c[:3]]))
+        if not ok:
+            return [self.forward(q, k, v, tp, None, want_idx=False)[0] for q, k, v, tp in calls]
+        B = q0.shape[0]
+        qm = ops.nchw_to_quads_grouped([[c[j].float() for c in calls] for j in range(3)])
+        tp = torch.cat([c[3].contiguous() for c in calls], 0)
+        msg = ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, hw_q, hw_k, self.nhead, None)
+        return [msg[g * B:(g + 1) * B] for g in range(len(calls))]
 
     def forward_tokens(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None, want_idx=True):
         """Token-major entry point: q [N,h0*w0,C], k/v [N,h1*w1,C].  Inference only."""

@@ -299,14 +299,14 @@ def qta_fine_level(q, key, value, prev_idx, hw0, hw1, nhead, topk, w_level=None,
 
 def nchw_to_quads_multi(xs, tokens=None):
     """list of [B,C_i,h_i,w_i] (same B; C_i % 32 == 0, h_i and w_i even) -> list of quad-major per-head tensors
-    [B, C_i/32, (h_i/2)*(w_i/2), 4, 32] (include/casmtr_hip.h), one launch for up to 9 tensors.
+    [B, C_i/32, (h_i/2)*(w_i/2), 4, 32] (include/casmtr_hip.h), one launch for up to 18 tensors.
     tokens: optional list of bools, True = convert that tensor to plain token-major [B, h_i*w_i, C_i] instead (same launch)."""
     import ctypes as C
     outs = []
     tokens = [False] * len(xs) if tokens is None else list(tokens)
-    for j in range(0, len(xs), 9):
-        chunk = [x if x.is_contiguous() else x.contiguous() for x in xs[j:j + 9]]
-        tk = tokens[j:j + 9]
+    for j in range(0, len(xs), 18):
+        chunk = [x if x.is_contiguous() else x.contiguous() for x in xs[j:j + 18]]
+        tk = tokens[j:j + 18]
         for x in chunk:
             _chk(x, "x")
         B = chunk[0].shape[0]
@@ -324,6 +324,45 @@ def nchw_to_quads_multi(xs, tokens=None):
                                                              n, B, _stream()),
                        "nchw_to_quads_multi")
         outs += res
+    return outs
+
+
+def nchw_to_quads_grouped(groups, tokens=None):
+    """groups: list (one entry per OUTPUT) of G same-shaped [B,C,h,w] tensors -> list of outputs [G*B, ...] (quad-major per head, or
+    token-major where tokens[i]): source g of output i lands in rows [g*B, (g+1)*B) -- the two directions of an attention layer share one
+    layout launch and every later kernel runs once on the doubled batch.  Up to 18 source tensors per launch."""
+    import ctypes as C
+    tokens = [False] * len(groups) if tokens is None else list(tokens)
+    G = len(groups[0])
+    if any(len(g) != G for g in groups):
+        raise RuntimeError("nchw_to_quads_grouped: every output needs the same number of sources")
+    srcs, dsts, outs = [], [], []
+    for grp, t in zip(groups, tokens):
+        grp = [x if x.is_contiguous() else x.contiguous() for x in grp]
+        for x in grp:
+            _chk(x, "x")
+        B, Cc, h, w = grp[0].shape
+        if any(tuple(x.shape) != (B, Cc, h, w) for x in grp):
+            raise RuntimeError("nchw_to_quads_grouped: the sources of one output must share their shape")
+        out = torch.empty((G * B, h * w, Cc) if t else (G * B, Cc // 32, (h // 2) * (w // 2), 4, 32), device=grp[0].device, dtype=torch.float32)
+        outs.append(out)
+        per = out[0].numel() * B * 4   # bytes of one source's share
+        for g, x in enumerate(grp):
+            srcs.append(x)
+            dsts.append((out.data_ptr() + g * per, t))
+    B = srcs[0].shape[0]
+    if any(x.shape[0] != B for x in srcs):
+        raise RuntimeError("nchw_to_quads_grouped: tensors must share the batch size")
+    for j in range(0, len(srcs), 18):
+        cs, cd = srcs[j:j + 18], dsts[j:j + 18]
+        n = len(cs)
+        arr = lambda vals, ty: C.cast((ty * n)(*vals), C.c_void_p)
+        with torch.cuda.device(cs[0].device):
+            _lib.check(_lib.lib().casmtr_nchw_to_quads_multi(arr([x.data_ptr() for x in cs], C.c_void_p), arr([d for d, _ in cd], C.c_void_p),
+                                                             arr([x.shape[1] for x in cs], C.c_int), arr([x.shape[2] for x in cs], C.c_int),
+                                                             arr([x.shape[3] for x in cs], C.c_int), arr([int(t) for _, t in cd], C.c_int),
+                                                             n, B, _stream()),
+                       "nchw_to_quads_multi")
     return outs
 
 

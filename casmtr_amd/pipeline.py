@@ -61,6 +61,9 @@ class HotPathConfig:
                                       # ([B,N,C] tokens in; q/k/v + output projections and the pyramid inside the step)
     masked: bool = False              # MegaDepth-style padding masks (BASELINE configs[2]): bottom / right up to 20 % padded
     fresh_inputs: bool = True         # every attention layer reads its own q/k/v tensors (False: one shared set, as round 1)
+    paired_layers: bool = True        # the two directions of a layer (independent in the reference, transformer.py:295-300 / :549) share
+                                      # their launches: one layout pass, every level kernel once on the doubled batch.  Off: measured
+                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs)
     implicit_windows: bool = True     # cascade window lists travel as topk_pos [B,N/4,25,2]; the int64 [B,N,100]
                                       # upsampled_idx is never written (False: the reference's data flow)
 
@@ -236,6 +239,10 @@ class HotPath(torch.nn.Module):
         for layer in range(cfg.coarse_layers):
             li = layer if cfg.fresh_inputs else 0
             pairs = ((0, 0), (1, 1)) if layer % 2 == 0 else ((0, 1), (1, 0))   # 'self' / 'cross'
+            if not cfg.callers and cfg.paired_layers:
+                # the two directions of a layer are independent in the reference (transformer.py:295-300): shared launches
+                msgs += self.qta.forward_multi([(inp[f"cq{a}"][li], inp[f"ck{b}"][li], inp[f"cv{b}"][li]) for a, b in pairs])
+                continue
             for a, b in pairs:
                 if cfg.callers:
                     msgs.append(self.coarse_blocks[layer](inp[f"cx{a}"], inp[f"cx{b}"], h8, w8))
@@ -262,6 +269,10 @@ class HotPath(torch.nn.Module):
                     blk = self.cascade_blocks[si][layer]
                     m0, i01 = blk(inp[f"{lvl}x0"], inp[f"{lvl}x1"], h, w, idx=tp01, rel_pos=rel01, want_idx=want_idx)
                     m1, i10 = blk(inp[f"{lvl}x1"], inp[f"{lvl}x0"], h, w, idx=tp10, rel_pos=rel10, want_idx=want_idx)
+                elif cfg.paired_layers and not want_idx and rel01 is None and rel10 is None:
+                    m0, m1 = self.cascade_qta[si].forward_multi([(inp[f"{lvl}q0"][li], inp[f"{lvl}k1"][li], inp[f"{lvl}v1"][li], tp01),
+                                                                 (inp[f"{lvl}q1"][li], inp[f"{lvl}k0"][li], inp[f"{lvl}v0"][li], tp10)])
+                    i01 = i10 = None
                 else:
                     att = self.cascade_qta[si]
                     m0, i01 = att(inp[f"{lvl}q0"][li], inp[f"{lvl}k1"][li], inp[f"{lvl}v1"][li], tp01, rel01, want_idx=want_idx)
