@@ -63,8 +63,10 @@ class HotPathConfig:
     fresh_inputs: bool = True         # every attention layer reads its own q/k/v tensors (False: one shared set, as round 1)
     paired_layers: bool = False       # the two directions of a layer (independent in the reference, transformer.py:295-300 / :549) share
                                       # their launches: one layout pass, every level kernel once on the doubled batch.  Off: measured
-                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs).  Off: measured
-                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs)
+                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs); the two
+                                      # directions on two HIP streams instead: 565 against 588.  Off: measured
+                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs); the two
+                                      # directions on two HIP streams instead: 565 against 588
     implicit_windows: bool = True     # cascade window lists travel as topk_pos [B,N/4,25,2]; the int64 [B,N,100]
                                       # upsampled_idx is never written (False: the reference's data flow)
 
