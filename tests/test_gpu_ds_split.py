@@ -129,3 +129,18 @@ def test_split_full_size_vs_exact(ops):
         assert n == int(ex["n"].item())
         assert torch.equal(sp["i_ids"][:n], ex["i_ids"][:n]) and torch.equal(sp["j_ids"][:n], ex["j_ids"][:n])
         assert float((sp["mconf"][:n] - ex["mconf"][:n]).abs().max()) < 1e-6 if n else True
+
+
+def test_split_low_threshold_uses_dense_pass(ops):
+    """thr < 1e-3: the sparse pass 2 (whose segment test needs log(thr * rsum)) hands over to the dense one; same lists as the exact path"""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    B, h, w, C = 2, 20, 24, 256
+    f0 = torch.randn((B, h * w, C), generator=g).to(DEV)
+    f1 = (f0[:, torch.randperm(h * w, generator=g)] + 0.3 * torch.randn((B, h * w, C), generator=g).to(DEV)).contiguous()
+    for thr in (0.0, 5e-4):
+        ex = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=False, gemm="exact")
+        sp = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=False, gemm="split")
+        n = int(sp["n"].item())
+        assert n == int(ex["n"].item()) and n > 100
+        assert torch.equal(sp["i_ids"][:n], ex["i_ids"][:n]) and torch.equal(sp["j_ids"][:n], ex["j_ids"][:n])
+        assert torch.equal(sp["next_idx_c01"], ex["next_idx_c01"]) and torch.equal(sp["next_idx_c10"], ex["next_idx_c10"])
