@@ -96,7 +96,7 @@ int casmtr_qta_fine_level_fwd(const float* q, const float* key, const float* val
  * previous level are one contiguous 512-byte run, a (pair, head) slice is contiguous.
  *
  * casmtr_nchw_to_quads_multi: src_i [B, C_i, h_i, w_i] (the module's NCHW pyramids) -> dst_i [B, C_i/32, (h_i/2)*(w_i/2), 4, 32];
- *   the `rearrange(...)` calls of :165-167,185-189 folded into one layout pass.  src/dst/C/h/w: HOST arrays of length n <= 9;
+ *   the `rearrange(...)` calls of :165-167,185-189 folded into one layout pass.  src/dst/C/h/w: HOST arrays of length n <= 18 (both directions of a layer in one launch);
  *   tokens (nullable HOST array): tokens[i] != 0 converts tensor i to plain token-major [B, h_i*w_i, C_i] instead (the coarsest
  *   level's operands), so that ONE launch serves a whole QTAttB call.                                                                */
 int casmtr_nchw_to_quads_multi(const float* const* src, float* const* dst, const int* C, const int* h, const int* w, const int* tokens,
