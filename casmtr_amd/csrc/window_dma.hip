@@ -51,12 +51,13 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
     int KW, int dil, int nquads, int dbg) {
     constexpr int NCH = C / 32, NPASS = NP1 > 0 ? 2 : 1, NS = NCH * NPASS;
     constexpr int QV = (C + 255) / 256;                        // float4s of a child's query row per lane
-    constexpr int WAVE_FLOATS = 4 * C + 2 * 64 + 2 * 2048;   // queries [4][C] | window positions [parity][32][2] | 2 x [64 rows][32]
+    constexpr int QS = C + 4;                                 // query row stride: the 4 children's rows (broadcast reads, lane % 4) in different banks
+    constexpr int WAVE_FLOATS = 4 * QS + 2 * 64 + 2 * 2048;  // queries [4][QS] | window positions [parity][32][2] | 2 x [64 rows][32]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* qn = smem + wave * WAVE_FLOATS;
-    int* ptab = reinterpret_cast<int*>(qn + 4 * C);
+    int* ptab = reinterpret_cast<int*>(qn + 4 * QS);
     float* buf = reinterpret_cast<float*>(ptab + 2 * 64);
     const int N = h0 * w0, S = h1 * w1, K = 4 * KW, wq = w0 >> 1;
     const int xcd = blockIdx.x & 7, chunk = (nquads + 7) >> 3;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
         for (int f = 0; f < 4; ++f)
 #pragma unroll
             for (int i = 0; i < QV; ++i)
-                if (qlane || i + 1 < QV) *reinterpret_cast<f32x4*>(qn + f * C + (i * 64 + lane) * 4) = q_nx[f][i];
+                if (qlane || i + 1 < QV) *reinterpret_cast<f32x4*>(qn + f * QS + (i * 64 + lane) * 4) = q_nx[f][i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
             f32x4 kr[8];          // operand B: this lane's candidate row chunk; operand A (qa): lane l holds qn[child l%4][c]
             if constexpr (p == 0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qp + (lane & 3) * C + ch * 32 + 4 * u);
+                for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qp + (lane & 3) * QS + ch * 32 + 4 * u);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(bp + rd[u]);
@@ -289,7 +290,7 @@ static int launch_wm_pos(const float* fq, const float* fk, const int64_t* tp, co
                          hipStream_t s) {
     const float sqrtC = (float)sqrt((double)C);
     const int nquads = (h0 / 2) * (w0 / 2);
-    const size_t lds = sizeof(float) * 2 * (4 * C + 2 * 64 + 2 * 2048);
+    const size_t lds = sizeof(float) * 2 * (4 * (C + 4) + 2 * 64 + 2 * 2048);
     static int resident_tab[CASMTR_MAX_DEVICES] = {0};   // persistent grid: exactly the workgroups that are resident at once
     int resident = 0;
     if (const int r = resident_workgroups(resident_tab, window_match_pos_kernel<C, RECIP, NP1>, 128, lds, &resident)) return r;
