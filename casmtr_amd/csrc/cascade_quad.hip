@@ -45,14 +45,15 @@ template <bool HAS_REL>
 __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(const CasQArgs a) {
     constexpr int KW = 25, KS = 128 + 4, PST = 64 + 4, SLOT_FLOATS = 8 * PST;   // per query slot: P[child][parity][64] / logits [4][KS]
     static_assert(SLOT_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
-    constexpr int WAVE_FLOATS = 2048 + 2 * SLOT_FLOATS + 2 * 128 + 32;
+    constexpr int QST = 36;               // query row stride: the 4 children's rows (lane % 4 broadcast reads) in different banks
+    constexpr int WAVE_FLOATS = 2048 + 2 * SLOT_FLOATS + 2 * 4 * QST + 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* ring = smem + wave * WAVE_FLOATS;                // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
     float* Pld = ring + 2048;                               // [2 query slots][SLOT_FLOATS]
-    float* qs = Pld + 2 * SLOT_FLOATS;                      // [2 query slots][4 children][32]
-    int* t2 = reinterpret_cast<int*>(qs + 256);             // t2[parity * 16 + j] = cell 2j + parity
+    float* qs = Pld + 2 * SLOT_FLOATS;                      // [2 query slots][4 children][QST]
+    int* t2 = reinterpret_cast<int*>(qs + 2 * 4 * QST);             // t2[parity * 16 + j] = cell 2j + parity
     const int H = a.H, HD = H * 32, L = a.h0 * a.w0, wq = a.w0 >> 1, Lq = a.nquads, h1p = a.h1 >> 1, w1p = a.w1 >> 1;
     // ---- work list: XCD x -> head x % H; the 8 / H XCDs sharing a head split every image pair's quad pairs into contiguous chunks
     const int xcd = blockIdx.x & 7, h = xcd % H, G = 8 / H, g = xcd / H;
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             }
         }
         // queries: slot 0 <- the lower half's (or quad B's when it runs alone), slot 1 <- the upper half's
-        if (sub_nx.nq == 2) *reinterpret_cast<f32x4*>(qs + lane * 4) = pf_q;
-        else if ((lane < 32) == q_lo) *reinterpret_cast<f32x4*>(qs + e * 4) = pf_q;
+        if (sub_nx.nq == 2) *reinterpret_cast<f32x4*>(qs + (lane >> 3) * QST + (lane & 7) * 4) = pf_q;
+        else if ((lane < 32) == q_lo) *reinterpret_cast<f32x4*>(qs + (e >> 3) * QST + (e & 7) * 4) = pf_q;
         wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
                 for (int hf = 0; hf < 2; ++hf) {   // operand A in two halves of 16 d (16 VGPRs instead of 32): lane l holds q[slot][child l%4][d]
                     f32x4 qa[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + sl * 128 + (lane & 3) * 32 + 16 * hf + 4 * u);
+                    for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (sl * 4 + (lane & 3)) * QST + 16 * hf + 4 * u);
                     lds_reads_done();
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
 
 template <bool HAS_REL>
 static int launch_cas_quad(const CasQArgs& a, hipStream_t s) {
-    constexpr size_t lds = 2 * sizeof(float) * (2048 + 2 * 8 * 68 + 2 * 128 + 32);
+    constexpr size_t lds = 2 * sizeof(float) * (2048 + 2 * 8 * 68 + 2 * 4 * 36 + 32);
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
     if (const int r = resident_workgroups(resident, cascade_quad_kernel<HAS_REL>, 128, lds, &res)) return r;

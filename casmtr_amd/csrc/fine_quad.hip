@@ -98,7 +98,8 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     constexpr int P_FLOATS = 8 * PST;
     constexpr int NV = 2 * NPASS;         // V chunks per item
     static_assert(P_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
-    constexpr int WAVE_FLOATS = 2048 + P_FLOATS + 128 + 32;
+    constexpr int QST = 36;               // query row stride: the 4 children's rows (lane % 4 broadcast reads) in different banks
+    constexpr int WAVE_FLOATS = 2048 + P_FLOATS + 4 * QST + 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // two INDEPENDENT waves per workgroup (no block barrier anywhere): LDS is granted in coarse granules, and one wave's 9.8 KB
     // (11 KB with lists > 64) rounded up alone leaves room for 13 single-wave workgroups per CU, two together for 16 (12) waves
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* ring = smem + wave * WAVE_FLOATS;                // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
     float* Pld = ring + 2048;                               // P[child][parity][m] (candidate 2m + parity); first the [4][KS] logits
-    float* qs = Pld + P_FLOATS;                             // [4 children][32]
-    int* t2 = reinterpret_cast<int*>(qs + 128);             // t2[parity * 16 + j] = parent 2j + parity
+    float* qs = Pld + P_FLOATS;                             // [4 children][QST]
+    int* t2 = reinterpret_cast<int*>(qs + 4 * QST);             // t2[parity * 16 + j] = parent 2j + parity
     const int H = a.H, HD = H * 32, Kp = a.Kp, K = 4 * Kp;
     const int L = a.h0 * a.w0, wq = a.w0 >> 1, Lq = a.nquads, w1p = a.w1 >> 1;
     // ---- work list: XCD x -> head x % H; the 8 / H XCDs sharing a head split every pair's quads into contiguous chunks
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     auto stage_in = [&]() {
         if (lane < 32) {
             t2[(lane & 1) * 16 + (lane >> 1)] = pf_p;
-            *reinterpret_cast<f32x4*>(qs + lane * 4) = pf_q;
+            *reinterpret_cast<f32x4*>(qs + (lane >> 3) * QST + (lane & 7) * 4) = pf_q;
         }
         acc_nx = pf_acc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             if constexpr (p == 0) flush();
             f32x4 qa[8], kr[8];   // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row
 #pragma unroll
-            for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * 32 + 4 * u);
+            for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * QST + 4 * u);
 #pragma unroll
             for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ring) + rd[u]);
             lds_reads_done();
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
 
 template <int NPASS, bool EXACT>
 static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
-    constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 128 + 32);
+    constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 4 * 36 + 32);
     // persistent grid: exactly the workgroups that are resident at once
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
