@@ -28,6 +28,7 @@ SIGNATURES = {
     "casmtr_nchw_to_tokens_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "casmtr_qta_coarse_level_fwd": (_I, [_P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_qta_coarse_level_ws_floats": (_SZ, [_I] * 4),
+    "casmtr_qta_coarse_level_ws_floats_k": (_SZ, [_I] * 5),
     "casmtr_qta_fine_level_fwd": (_I, [_P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "casmtr_nchw_to_quads_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "casmtr_tokens_to_quads": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -111,7 +112,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if l.casmtr_abi_version() != 3:
+        if l.casmtr_abi_version() != 4:
             raise RuntimeError("libcasmtr_hip.so ABI version mismatch")
         _lib = l
     return _lib

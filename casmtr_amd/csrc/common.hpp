@@ -13,13 +13,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace casmtr {
 
 // Order-preserving map float -> uint32 (total order of the finite floats; -0 < +0, irrelevant for us).
-__device__ __forceinline__ unsigned f2ord(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+__device__ __forceinline__ unsigned f2ord(float f) {   // branch-free: 3 VALU (the ?: form compiles to cmp + not + or + cndmask)
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);   // negative: ~u, otherwise u | 0x80000000
 }
 __device__ __forceinline__ float ord2f(unsigned o) {
-    unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return __uint_as_float(u);
+    const unsigned t = (unsigned)((int)o >> 31) & 0x7fffffffu;   // top bit set (was >= +0): flip it only; clear: ~o
+    return __uint_as_float(~(o ^ t));
 }
 
 // DPP controls (gfx9): quad_perm = 0x00..0xFF, row_shr:n = 0x110+n, row_mirror 0x140, row_half_mirror 0x141,

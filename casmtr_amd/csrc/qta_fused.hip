@@ -727,23 +727,32 @@ __global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict_
     }
 }
 
-// coarse_fused.hip
+// coarse_fused.hip / coarse_tile.hip
 int casmtr_qta_coarse_level_fused(const float* q, const float* k, const float* v, float temp, int topk, float w_level, float* message,
                                   float* acc_out, float* topk_score, int64_t* topk_idx, int B, int L, int S, int H, hipStream_t s);
+int casmtr_qta_coarse_level_tile(const float* q, const float* k, const float* v, float temp, int topk, float w_level, float* message,
+                                 float* acc_out, float* topk_score, int64_t* topk_idx, int32_t* topk_tab, int B, int L, int S, int H,
+                                 hipStream_t s);
 
-// default: the three-kernel path below; CASMTR_COARSE_KERNEL=fused selects the single-kernel path (coarse_fused.hip, S <= 1024).
-// Measured at 26x26, H = 8, B = 8: 153 us per call against 206 us fused -- the [B,H,L,S_pad] workspace (122 MB) stays in the
-// 256 MB Infinity Cache between the three kernels, so its four passes are cheap, while the fused kernel at 3 workgroups per CU
-// exposes the latency of its operand loads; the row phase (softmax + top-32) costs the same ~57 us in both.  Read per call.
-static bool coarse_use_fused(int S) {
+// Three implementations, identical indices.  Default (round 4): the register-tile kernel (coarse_tile.hip: logits born in the
+// selection's layout, no workspace; S <= 1024, topk <= 60).  CASMTR_COARSE_KERNEL=three selects the round-1 three-kernel path below
+// (also the fallback for shapes outside the tile kernel), =fused the round-2 LDS-tile kernel (coarse_fused.hip).  Read per call.
+// Measured at 26x26, H = 8, B = 8: three kernels 143-153 us per call, fused 197-206 us (see DESIGN.md for the tile kernel).
+enum { COARSE_TILE = 0, COARSE_THREE = 1, COARSE_FUSED = 2 };
+static int coarse_mode(int S, int topk) {
     const char* ev = getenv("CASMTR_COARSE_KERNEL");
-    return ev && !strcmp(ev, "fused") && S <= 1024;
+    if (ev && !strcmp(ev, "fused") && S <= 1024) return COARSE_FUSED;
+    if (ev && !strcmp(ev, "three")) return COARSE_THREE;
+    return (S <= 1024 && topk >= 1 && topk <= 60 && topk <= S) ? COARSE_TILE : COARSE_THREE;
 }
 
-extern "C" size_t casmtr_qta_coarse_level_ws_floats(int B, int L, int S, int H) {
-    if (coarse_use_fused(S)) return 1;
+extern "C" size_t casmtr_qta_coarse_level_ws_floats_k(int B, int L, int S, int H, int topk) {
+    if (coarse_mode(S, topk) != COARSE_THREE) return 1;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;
     return (size_t)B * H * L * Spad + 2 * (size_t)B * H * L;   // logits + per-row (max, sum)
+}
+extern "C" size_t casmtr_qta_coarse_level_ws_floats(int B, int L, int S, int H) {   // topk unknown: the three-kernel path's need
+    return casmtr_qta_coarse_level_ws_floats_k(B, L, S, H, 0);
 }
 
 extern "C" int casmtr_topk_idx_to_tab(const int64_t* idx, int32_t* tab, int B, int L, int K, int H, casmtr_stream_t stream);
@@ -763,11 +772,17 @@ extern "C" int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, c
     if (D != 32 || topk > S) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (coarse_use_fused(S)) {
+    const int mode = coarse_mode(S, topk);
+    if (mode == COARSE_TILE) {
+        const int r = casmtr_qta_coarse_level_tile(q, k, v, temp, topk, w_level, message, acc_out, topk_score, topk_idx, topk_tab, B, L, S, H, s);
+        if (r != CASMTR_ERR_UNSUPPORTED) return r;
+    }
+    if (mode == COARSE_FUSED && topk_score && topk_idx) {
         const int r = casmtr_qta_coarse_level_fused(q, k, v, temp, topk, w_level, message, acc_out, topk_score, topk_idx, B, L, S, H, s);
         if (r == 0 && topk_tab) return casmtr_topk_idx_to_tab(topk_idx, topk_tab, B, L, topk, H, stream);
         if (r != CASMTR_ERR_UNSUPPORTED) return r;
     }
+    if (!logits_ws || !topk_score || !topk_idx) return CASMTR_ERR_UNSUPPORTED;   // the three-kernel path needs its workspace and writes both lists
     const int Spad = (S + 63) / 64 * 64;
     {
         ProfScope ps(CASMTR_PROF_COARSE_LOGITS, s);

@@ -186,7 +186,7 @@ class QTAttB(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):   # high priority: its small kernels get the slots the layout pass keeps freeing
                 coarse = ops.nchw_to_quads_multi(flat[:3], [True] * 3)
-                out = ops.qta_coarse_level(*coarse, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True)
+                out = ops.qta_coarse_level(*coarse, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=want_topk)
             fine = ops.nchw_to_quads_multi(flat[3:], [False] * (len(flat) - 3))
             conv = iter(coarse + fine)
         else:
@@ -201,7 +201,7 @@ class QTAttB(nn.Module):
                 laid.append(next(conv))
         (q0, k0, v0), quads = laid[:3], laid[3:]
         if side is None:
-            out = ops.qta_coarse_level(q0, k0, v0, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True)
+            out = ops.qta_coarse_level(q0, k0, v0, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=want_topk)
         else:
             torch.cuda.current_stream().wait_stream(side)
             for t in list(out.values()) + [q0, k0, v0]:   # allocated on the side stream, consumed (and later freed) on this one
@@ -241,7 +241,7 @@ class QTAttB(nn.Module):
     def _run_levels_quad(self, coarse, quads, hw_q, hw_k, want_topk):
         n = len(hw_q)
         weight = self._level_weights()
-        out = ops.qta_coarse_level(*coarse, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True)
+        out = ops.qta_coarse_level(*coarse, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=want_topk)
         acc, tab = out["acc"], out["topk_tab"]
         per_level = [out]
         for i in range(1, n):

@@ -257,24 +257,33 @@ def pola_attn(q, k0, v0, bias_table, H, W, nhead, ws, scale):
     return y
 
 
-def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True, want_tab=False):
+def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True, want_tab=False, want_topk=True):
     """q [B,L,C], k/v [B,S,C] tokens -> dict(message, acc, topk_score, topk_idx, topk_tab, probs_ws).
-    want_tab: also the compact per-head table [B,H,L,topk] int32 that qta_fine_level_quad takes as `parents`."""
+    want_tab: also the compact per-head table [B,H,L,topk] int32 that qta_fine_level_quad takes as `parents`.
+    want_topk=False: the reference's [B,L,topk,H] score / int64 index tensors (:170-175) are not written (the fused module path
+    hands the lists on as the int32 table); honoured by the default kernel, the three-kernel path always writes them."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
     B, L, Cc = q.shape
     S, D = k.shape[1], Cc // nhead
     l = _lib.lib()
-    ws = torch.empty(l.casmtr_qta_coarse_level_ws_floats(B, L, S, nhead), device=q.device, dtype=torch.float32)
+    n_ws = l.casmtr_qta_coarse_level_ws_floats_k(B, L, S, nhead, topk)
+    want_topk = want_topk or n_ws > 1 or not want_tab
+    ws = torch.empty(n_ws, device=q.device, dtype=torch.float32)
     msg = torch.empty((B, L, nhead, D), device=q.device, dtype=torch.float32) if want_message else None
     acc = torch.empty((B, L, nhead, D), device=q.device, dtype=torch.float32) if w_level is not None else None
-    ts = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.float32)
-    ti = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.int64)
     tab = torch.empty((B, nhead, L, topk), device=q.device, dtype=torch.int32) if want_tab else None
-    with torch.cuda.device(q.device):
-        _lib.check(l.casmtr_qta_coarse_level_tab_fwd(_ptr(q), _ptr(k), _ptr(v), 1.0 / D ** 0.5, topk,
-                                                     0.0 if w_level is None else float(w_level), _ptr(ws), _ptr(msg),
-                                                     _ptr(acc), _ptr(ts), _ptr(ti), _ptr(tab), B, L, S, nhead, D, _stream()),
-                   "qta_coarse_level_fwd")
+    while True:
+        ts = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.float32) if want_topk else None
+        ti = torch.empty((B, L, topk, nhead), device=q.device, dtype=torch.int64) if want_topk else None
+        with torch.cuda.device(q.device):
+            rc = l.casmtr_qta_coarse_level_tab_fwd(_ptr(q), _ptr(k), _ptr(v), 1.0 / D ** 0.5, topk,
+                                                   0.0 if w_level is None else float(w_level), _ptr(ws), _ptr(msg),
+                                                   _ptr(acc), _ptr(ts), _ptr(ti), _ptr(tab), B, L, S, nhead, D, _stream())
+        if rc == _lib.ERR_UNSUPPORTED and not want_topk:   # a kernel variant that cannot skip the lists (CASMTR_COARSE_KERNEL=fused)
+            want_topk = True
+            continue
+        _lib.check(rc, "qta_coarse_level_fwd")
+        break
     return dict(message=msg, acc=acc, topk_score=ts, topk_idx=ti, topk_tab=tab, probs_ws=ws)
 
 

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 3
+#define CASMTR_ABI_VERSION 4
 int casmtr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -116,7 +116,12 @@ int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, const float
                                    int topk, float w_level, const float* acc_in, float* message, float* acc_out,
                                    int32_t* topk_tab, float* topk_score, int64_t* topk_idx, int B, int h0, int w0, int h1,
                                    int w1, int H, int D, int Kp, casmtr_stream_t stream);
-/* casmtr_qta_coarse_level_fwd with one more output: topk_tab nullable [B,H,L,topk] int32 (the finer level's `parents`)               */
+/* casmtr_qta_coarse_level_fwd with one more output: topk_tab nullable [B,H,L,topk] int32 (the finer level's `parents`).  Default
+ * kernel (round 4, csrc/coarse_tile.hip; S <= 1024, topk <= 60): one launch, no workspace -- logits_ws may then be a 1-float dummy
+ * (casmtr_qta_coarse_level_ws_floats_k says so) and topk_score / topk_idx may be NULL (the reference's int64 lists :170-175 are only
+ * written on request).  Other shapes, or CASMTR_COARSE_KERNEL=three: the three-kernel path, which needs the workspace and both lists
+ * (CASMTR_ERR_UNSUPPORTED otherwise).                                                                                                  */
+size_t casmtr_qta_coarse_level_ws_floats_k(int B, int L, int S, int H, int topk);
 int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, const float* v, float temp, int topk, float w_level,
                                     float* logits_ws, float* message, float* acc_out, float* topk_score,
                                     int64_t* topk_idx, int32_t* topk_tab, int B, int L, int S, int H, int D, casmtr_stream_t stream);

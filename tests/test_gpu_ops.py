@@ -473,16 +473,24 @@ def test_empty_batch_and_limits(ops):
         ops.window_match(z(1, 16, 64), z(1, 400, 64), torch.zeros((1, 16, 144), device=DEV, dtype=torch.int64))
 
 
-@pytest.mark.parametrize("kernel", ["fused", "split"])
-@pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid"])
+@pytest.mark.parametrize("kernel", ["tile", "three", "fused"])
+@pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid", "wide_range", "indoor", "ragged", "tiny"])
 def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
-    """coarse-level top-k: the bitonic fast path (<= 64 survivors of the lane-maxima threshold) and the iterative fallback
-    (ties / concentrated rows) must both return the oracle's list, ordered (logit desc, position asc)"""
-    monkeypatch.setenv("CASMTR_COARSE_KERNEL", kernel)   # single fused kernel | default logits / row / A.V kernels
-    r = np.random.default_rng({"random": 1, "all_equal": 2, "one_lane_heavy": 3, "many_ties": 4, "few_valid": 5}[kind])
+    """coarse-level top-k: the sorted fast path (<= 64 survivors of the lane-maxima threshold; in the tile kernel the exact 32-bit
+    packing) and the fallbacks (ties / concentrated rows: iterated argmax; survivors spread over many binades: pair sort) must all
+    return the oracle's list, ordered (logit desc, position asc)"""
+    monkeypatch.setenv("CASMTR_COARSE_KERNEL", kernel)   # round-4 register-tile kernel (default) | logits / row / A.V kernels | LDS-tile kernel
+    r = np.random.default_rng({"random": 1, "all_equal": 2, "one_lane_heavy": 3, "many_ties": 4, "few_valid": 5, "wide_range": 6,
+                               "indoor": 7, "ragged": 8, "tiny": 9}[kind])
     B, H, L, S, topk = 1, 2, 40, 676, 32
     if kind == "few_valid":
-        S, topk = 48, 8          # fewer keys than lanes: theta == 0 -> fallback
+        S, topk = 48, 8          # fewer keys than lanes
+    elif kind == "indoor":
+        B, H, L, S = 2, 8, 300, 300   # 20 x 15 grid (configs[4]): 5 key blocks, the last one partial, 19 row tiles
+    elif kind == "ragged":
+        L, S, topk = 37, 131, 16      # nothing a multiple of anything
+    elif kind == "tiny":
+        L, S, topk = 16, 16, 8        # 4 x 4 coarsest grid of the small fixtures
     q = r.standard_normal((B, L, H, 32)).astype(np.float32)
     k = r.standard_normal((B, S, H, 32)).astype(np.float32)
     v = r.standard_normal((B, S, H, 32)).astype(np.float32)
@@ -493,13 +501,25 @@ def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
         q[:] = q[:, :1]                      # same query everywhere so that the boost lines up
     elif kind == "many_ties":
         k[:, ::2] = k[:, 1::2]               # every logit appears twice
+    elif kind == "wide_range":
+        # the 40 best logits of a row span 20+ binades (ordered keys further apart than 2^26): keys = query direction x 2^-j
+        k[:, :40] = q[:, :1].mean(axis=1, keepdims=True) * (2.0 ** -np.arange(40, dtype=np.float32))[None, :, None, None] * 8.0
+        k[:, 40:] *= 1e-9
+        q[:] = q[:, :1]
     C = H * 32
     o = oracle.qta_coarse_level(q, k, v, topk)
-    out = ops.qta_coarse_level(T(q.reshape(B, L, C)), T(k.reshape(B, S, C)), T(v.reshape(B, S, C)), H, topk, w_level=1.0)
+    out = ops.qta_coarse_level(T(q.reshape(B, L, C)), T(k.reshape(B, S, C)), T(v.reshape(B, S, C)), H, topk, w_level=1.0, want_tab=True)
     assert np.array_equal(N(out["topk_idx"]), o[2]), kind
+    assert np.array_equal(N(out["topk_tab"]), o[2].transpose(0, 3, 1, 2)), "int32 table [B,H,L,topk]"
     assert_close(N(out["topk_score"]), o[1], SOFTMAX_TOL, "topk_score")
     assert_close(N(out["message"]), o[0], SOFTMAX_TOL, "message")
     assert_close(N(out["acc"]), o[0], SOFTMAX_TOL, "message * weight")
+    if kernel == "tile":   # the lists on request only: table-only call, same table
+        out2 = ops.qta_coarse_level(T(q.reshape(B, L, C)), T(k.reshape(B, S, C)), T(v.reshape(B, S, C)), H, topk, w_level=0.5,
+                                    want_message=False, want_tab=True, want_topk=False)
+        assert out2["topk_idx"] is None and out2["message"] is None
+        assert np.array_equal(N(out2["topk_tab"]), o[2].transpose(0, 3, 1, 2))
+        assert_close(N(out2["acc"]), o[0] * np.float32(0.5), SOFTMAX_TOL, "message * 0.5")
 
 
 @pytest.mark.parametrize("kernel", ["quad", "dma"])

@@ -1,5 +1,6 @@
-"""Times the coarsest QTAttB level (26x26, H=8, top-32, B=8) for the fused and the three-kernel path; casmtr_debug_set bits on the
-fused kernel: 1 = stop after the logits phase, 2 = skip the row phase, 4 = stop before A.V."""
+"""Times the coarsest QTAttB level (26x26, H=8, top-32, B=8) for the register-tile kernel (default), the three-kernel path and the
+LDS-tile kernel; casmtr_debug_set bits: fused kernel 1 = stop after the logits phase, 2 = skip the row phase, 4 = stop before A.V;
+tile kernel 256 = skip the selection, 512 = skip the A.V arithmetic."""
 import os
 os.environ["CASMTR_DEBUG_HOOKS"] = "1"   # casmtr_debug_set() is ignored without this opt-in
 import os
@@ -28,9 +29,9 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for kern, flagset in (("split", (0,)), ("fused", (0, 1, 2, 4, 6))):
+for kern, flagset in (("tile", (0, 256, 512, 768)), ("three", (0,)), ("fused", (0, 1, 2, 4, 6))):
     os.environ["CASMTR_COARSE_KERNEL"] = kern
     for flags in flagset:
         _lib.lib().casmtr_debug_set(flags)
-        print(f"[{kern}] debug flags {flags}: {t(lambda: ops.qta_coarse_level(q, k, v, H, 32, w_level=0.3, want_message=False)):7.1f} us")
+        print(f"[{kern}] debug flags {flags}: {t(lambda: ops.qta_coarse_level(q, k, v, H, 32, w_level=0.3, want_message=False, want_tab=True, want_topk=False)):7.1f} us")
 _lib.lib().casmtr_debug_set(0)
