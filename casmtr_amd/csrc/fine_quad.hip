@@ -534,7 +534,8 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
                                               int w1, int H, int D, int Kp, casmtr_stream_t stream) {
     const int K = 4 * Kp;
     if (D != 32 || (h0 & 1) || (w0 & 1) || (h1 & 1) || (w1 & 1) || Kp < 1 || Kp > 32 || topk > K || topk > 16 ||
-        (H != 8 && H != 4 && H != 2 && H != 1) || (long long)(h1 / 2) * (w1 / 2) >= (1 << 22))
+        (H != 8 && H != 4 && H != 2 && H != 1) || (long long)(h1 / 2) * (w1 / 2) >= (1 << 22) ||
+        (long long)(h1 / 2) * (w1 / 2) * (w1 / 2) >= (1ll << 32))   // umulhi(p, ceil(2^32 / d)) == p / d needs p * d < 2^32 (p < lq1, d = w1 / 2)
         return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
     FineQArgs a{};

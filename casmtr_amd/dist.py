@@ -119,10 +119,14 @@ class MatchGatherer:
     """gather_matches() every `every` steps instead of every step: the lists of the steps in between stay on their rank (device
     tensors, tens of KB each) and travel in ONE exchange -- one counts all-gather, one host read-back and two padded gathers per
     `every` steps.  Pair ids in the gathered m_bids are step * pairs_per_step + global pair id, steps counted from the last flush.
-    every = 1 is the reference's behaviour (results leave the rank after every batch).  Single process: plain passthrough."""
+    every = 1 is the reference's behaviour (results leave the rank after every batch).  Single process: plain passthrough.
+    add() and flush() are COLLECTIVE: every rank calls them the same number of times (a rank that holds lists while another one
+    does not would deadlock the gather), and lists still held when the object is dropped are lost -- call flush() last."""
 
     def __init__(self, every=1, pair_offset=0, pairs_per_step=0, dst=0):
         self.every, self.pair_offset, self.pairs_per_step, self.dst = max(1, int(every)), int(pair_offset), int(pairs_per_step), dst
+        if self.every > 1 and self.pairs_per_step <= 0:
+            raise ValueError("MatchGatherer(every > 1) needs pairs_per_step > 0: the held steps' pair ids would collapse onto each other")
         self._held = []
 
     def add(self, out):

@@ -400,7 +400,8 @@ def topk_idx_to_tab(idx):
 def fine_quad_supported(nhead, head_dim, hw0, hw1, Kp, topk):
     """shapes the quad-major fine-level kernel covers (csrc/fine_quad.hip); anything else runs the token-major kernels"""
     return (head_dim == 32 and nhead in (1, 2, 4, 8) and all(v % 2 == 0 and v > 0 for v in (*hw0, *hw1)) and 1 <= Kp <= 32
-            and topk <= 16 and topk <= 4 * Kp and (hw1[0] // 2) * (hw1[1] // 2) < (1 << 22))
+            and topk <= 16 and topk <= 4 * Kp and (hw1[0] // 2) * (hw1[1] // 2) < (1 << 22)
+            and (hw1[0] // 2) * (hw1[1] // 2) * (hw1[1] // 2) < (1 << 32))   # the kernel's reciprocal division by w1 / 2
 
 
 def qta_fine_level_quad(q, key, value, parents, hw0, hw1, nhead, topk, w_level=None, acc_in=None, want_message=True,
@@ -474,12 +475,19 @@ def window_warp_idx(idx, H, W, ws=5):
     return out
 
 
-def ds_gemm_mode():
-    """'split' (default): similarity matrix on the f16 matrix pipe + exact re-decision of near-tie indices
-    (casmtr_dual_softmax_split_fwd); 'exact': fp32 MFMA = the oracle's fmaf chain for every entry.  Read per call."""
-    m = os.environ.get("CASMTR_DS_GEMM", "split")
+def ds_gemm_mode(requested=None):
+    """Which kernel computes CoarseMatching's similarity matrix.
+    'exact' (default): fp32 MFMA = the oracle's fmaf chain for every entry of the [L,S] matrix (casmtr_dual_softmax_fwd).
+    'split' (opt-in: CoarseMatching(gemm='split'), what the HotPath pipeline / bench.py select): the matrix on the f16 matrix pipe
+        (two-term f16 split, fp32-accurate) + exact re-decision of the near-tie ROW / COLUMN ARGMAX of the logits
+        (casmtr_dual_softmax_split_fwd).  What is exact there is `next_idx_c01` / `next_idx_c10`; probabilities, confidences and
+        therefore the thresholded mutual-max match list are computed from logits that differ by ~1e-6 from the exact path's: a
+        confidence within that distance of `thr`, or two confidences of a row / column that close together, can change the list
+        (same class of effect as the device exp against libm's in the exact path; tests audit such entries one by one).
+    The environment variable CASMTR_DS_GEMM, when set, overrides `requested` (bench legs, tests).  Read per call."""
+    m = os.environ.get("CASMTR_DS_GEMM") or requested or "exact"
     if m not in ("split", "exact"):
-        raise RuntimeError(f"CASMTR_DS_GEMM={m!r}: expected 'split' or 'exact'")
+        raise RuntimeError(f"dual-softmax GEMM mode {m!r}: expected 'split' or 'exact'")
     return m
 
 
@@ -493,7 +501,7 @@ def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=No
     S = feat1.shape[1]
     dev = feat0.device
     l = _lib.lib()
-    split = (gemm or ds_gemm_mode()) == "split"
+    split = ds_gemm_mode(gemm) == "split"
     sim = torch.empty((B, L, S), device=dev, dtype=torch.float32)
     ws = torch.empty(l.casmtr_dual_softmax_split_ws_bytes(B, L, S, Cc) if split else l.casmtr_dual_softmax_ws_bytes(B, L, S),
                      device=dev, dtype=torch.uint8)

@@ -64,9 +64,9 @@ class HotPathConfig:
     paired_layers: bool = False       # the two directions of a layer (independent in the reference, transformer.py:295-300 / :549) share
                                       # their launches: one layout pass, every level kernel once on the doubled batch.  Off: measured
                                       # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs); the two
-                                      # directions on two HIP streams instead: 565 against 588.  Off: measured
-                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs); the two
                                       # directions on two HIP streams instead: 565 against 588
+    ds_gemm: str = "split"            # CoarseMatching(gemm=...): 'split' = f16 matrix pipe + exact argmax re-decision (ops.ds_gemm_mode),
+                                      # 'exact' = every logit from the fp32 chain; CASMTR_DS_GEMM overrides (bench.py's exact leg)
     implicit_windows: bool = True     # cascade window lists travel as topk_pos [B,N/4,25,2]; the int64 [B,N,100]
                                       # upsampled_idx is never written (False: the reference's data flow)
 
@@ -211,7 +211,7 @@ class HotPath(torch.nn.Module):
         self.coarse_matching = CoarseMatching(
             {"thr": cfg.coarse_thr, "border_rm": cfg.coarse_border_rm, "train_coarse_percent": 0.3,
              "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.coarse_temperature},
-            materialize_conf=cfg.materialize_conf, defer_sync=True)  # one host sync per step, at the end
+            materialize_conf=cfg.materialize_conf, defer_sync=True, gemm=cfg.ds_gemm)  # one host sync per step, at the end
         self.cascade_matching = torch.nn.ModuleList()
         for st in cfg.stages:
             post = {"method": "maxpool_nms", "window_size": st.nms_window} if st.nms_window else {"method": None}

@@ -63,15 +63,16 @@ def test_cascade_module_vs_reference(name):
     assert torch.isfinite(q.grad).all()
 
 
+@pytest.mark.parametrize("gemm", [None, "split"])   # module default (exact fp32 chain for every logit) | opt-in f16 split + exact argmax re-decision
 @pytest.mark.parametrize("name", list(CASES["coarse_matching"]))
-def test_coarse_matching_module(name):
+def test_coarse_matching_module(name, gemm):
     from casmtr_amd.matching.coarse_matching import CoarseMatching
     inp = make_inputs("coarse_matching", name)
     cfg = CASES["coarse_matching"][name]
     g = load_golden("coarse_matching", name)
     mc = {"thr": cfg.get("thr", 0.2), "border_rm": cfg.get("border_rm", 0), "train_coarse_percent": 0.3,
           "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.get("T", 0.1)}
-    cm = CoarseMatching(mc, div_mode="cpu").eval()   # fixtures come from the reference on CPU
+    cm = CoarseMatching(mc, div_mode="cpu", gemm=gemm).eval()   # fixtures come from the reference on CPU
     h0, w0 = cfg["hw0"]
     h1, w1 = cfg["hw1"]
     data = {"hw0_i": (h0 * 8, w0 * 8), "hw1_i": (h1 * 8, w1 * 8), "hw0_8c": (h0, w0), "hw1_8c": (h1, w1)}
