@@ -28,6 +28,13 @@
 //     closer than 2^-16 relative -- redo the selection with the exact iterated argmax;
 //   V chunks (32 rows): 16 v_mfma_f32_4x4x1 each (two rows per instruction), probabilities as operand A from 4 ds_read_b128.
 // Results are in raster order of the h0 x w0 grid; final = final[parent] + message * weight (:277-281) fused into the store.
+//
+// Front end (round 4): the next item's queries, parent list and final[parent] row also arrive by LDS-DMA (4 x 256-byte
+// global_load_lds_dword into a double-buffered 1 KB staging area, issued at the START of the current item, consumed under its last
+// V chunks).  Round 3 fetched them with ordinary global loads into registers; the compiler cannot see the DMA instructions, so its
+// own `s_waitcnt vmcnt(0)` for those loads -- placed right behind them, where it copies the values into the loop-carried registers --
+// drained the whole DMA ring two or three times per item (profiles/r04_fine_quad_vmcnt.md).  Now the loop contains no
+// compiler-visible vector load at all (tools/check_quad_isa.py checks that).
 #include <stdio.h>
 #include <stdlib.h>
 #include "quad_common.hpp"
@@ -98,17 +105,16 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     constexpr int P_FLOATS = 8 * PST;
     constexpr int NV = 2 * NPASS;         // V chunks per item
     static_assert(P_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
-    constexpr int QST = 36;               // query row stride: the 4 children's rows (lane % 4 broadcast reads) in different banks
-    constexpr int WAVE_FLOATS = 2048 + P_FLOATS + 4 * QST + 32;
+    constexpr int STG = 256;              // staging buffer of one item: q [4][32] (16-byte units XOR-swizzled) | parents [64] | final[parent] [64]
+    constexpr int WAVE_FLOATS = 2048 + P_FLOATS + 2 * STG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // two INDEPENDENT waves per workgroup (no block barrier anywhere): LDS is granted in coarse granules, and one wave's 9.8 KB
-    // (11 KB with lists > 64) rounded up alone leaves room for 13 single-wave workgroups per CU, two together for 16 (12) waves
+    // two INDEPENDENT waves per workgroup (no block barrier anywhere): LDS is granted in coarse granules, and one wave's ~11 KB
+    // rounded up alone leaves room for fewer single-wave workgroups per CU than two together
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* ring = smem + wave * WAVE_FLOATS;                // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
     float* Pld = ring + 2048;                               // P[child][parity][m] (candidate 2m + parity); first the [4][KS] logits
-    float* qs = Pld + P_FLOATS;                             // [4 children][QST]
-    int* t2 = reinterpret_cast<int*>(qs + 4 * QST);             // t2[parity * 16 + j] = parent 2j + parity
+    float* stg = Pld + P_FLOATS;                            // [2][STG]
     const int H = a.H, HD = H * 32, Kp = a.Kp, K = 4 * Kp;
     const int L = a.h0 * a.w0, wq = a.w0 >> 1, Lq = a.nquads, w1p = a.w1 >> 1;
     // ---- work list: XCD x -> head x % H; the 8 / H XCDs sharing a head split every pair's quads into contiguous chunks
@@ -133,10 +139,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     for (int x = 0; x < 8; ++x) va[x] = (unsigned)((lane >> 5) * 128 + ((((lane & 31) >> 2) ^ x) * 16) + (lane & 3) * 4);
     const float* pa = Pld + ((lane & 3) * 2 + (lane >> 5)) * PST;   // operand A of the V chunks: P[child lane%4][parity lane/32][.]
 
-    // ---- per-item front end, run one item ahead: global -> registers (prefetch), registers -> LDS + DMA offsets (stage_in)
-    int pf_p = 0;
-    f32x4 pf_q = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float pf_acc = 0.f, acc_cur = 0.f, acc_nx = 0.f;   // final[parent] of the item for d = lane % 32 (:277)
+    // ---- per-item front end, one item ahead: global -> LDS staging (prefetch, DMA), staging -> DMA offsets (stage_in)
     struct Item { int b, quad, l00; };                  // pair, quad, first child's token (child f -> l00 + (f>>1)*w0 + (f&1))
     int cb = t / cnt, cq = t % cnt, cy = (g * chunk + cq) / wq, cx = (g * chunk + cq) % wq;
     const int sy = stride / wq, sx = stride % wq;
@@ -153,32 +156,30 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
         }
         return true;
     };
-    auto prefetch = [&](const Item& it) {
-        const size_t qd = ((size_t)it.b * H + h) * Lq + it.quad;
-        if (a.xflags & 1) {
-            if (lane < 32) {
-                pf_p = __builtin_nontemporal_load(a.parents + qd * Kp + min(lane, Kp - 1));
-                pf_q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.q + qd * 128 + lane * 4));
-            }
-            if (a.acc_in) pf_acc = __builtin_nontemporal_load(a.acc_in + ((size_t)it.b * Lq + it.quad) * HD + h * 32 + (lane & 31));
-            return;
-        }
-        if (lane < 32) {
-            pf_p = a.parents[qd * Kp + min(lane, Kp - 1)];
-            pf_q = *reinterpret_cast<const f32x4*>(a.q + qd * 128 + lane * 4);
-        }
-        if (a.acc_in) pf_acc = a.acc_in[((size_t)it.b * Lq + it.quad) * HD + h * 32 + (lane & 31)];
+    const unsigned stg_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(stg));
+    // lane constants of the 4 staging instructions (each: 64 lanes x 4 bytes, lane-linear destination)
+    unsigned qo[2];   // q: staging dword 64 k + lane = row r, physical unit pu, word wv  <-  logical unit pu ^ (r >> 1) (conflict-free A reads)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int pos = 64 * k + lane, r = pos >> 5, c = pos & 31;
+        qo[k] = (unsigned)((r * 32 + (((c >> 2) ^ (r >> 1)) * 4) + (c & 3)) * 4);
+    }
+    const unsigned po = (unsigned)(min(2 * (lane & 15) + ((lane >> 4) & 1), Kp - 1) * 4);   // staging dword parity * 16 + j <- parent 2 j + parity
+    const unsigned ao = (unsigned)((lane & 31) * 4);
+    auto dma4 = [&](const void* base, unsigned off, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(base), "s"(dst) : "memory");
+    };
+    auto prefetch = [&](const Item& it, int buf) {   // 4 (3 without acc_in) DMA instructions
+        const unsigned qd = (unsigned)((it.b * H + h) * Lq + it.quad);   // wave-uniform
+        const unsigned dst = stg_lds + (unsigned)(buf * STG * 4);
+        dma4(a.q, qd * 512u + qo[0], dst);
+        dma4(a.q, qd * 512u + qo[1], dst + 256u);
+        dma4(a.parents, qd * (unsigned)(Kp * 4) + po, dst + 512u);
+        if (a.acc_in) dma4(a.acc_in, (unsigned)((it.b * Lq + it.quad) * HD + h * 32) * 4u + ao, dst + 768u);
     };
     unsigned voff[NPASS][8];   // DMA instruction j of pass p: source offset of this lane's 16 bytes (rows 64p + 8j + lane/8)
-    auto stage_in = [&]() {
-        if (lane < 32) {
-            t2[(lane & 1) * 16 + (lane >> 1)] = pf_p;
-            *reinterpret_cast<f32x4*>(qs + (lane >> 3) * QST + (lane & 7) * 4) = pf_q;
-        }
-        acc_nx = pf_acc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto stage_in = [&](int buf) {   // the staged parent list -> this lane's DMA offsets
+        const int* t2 = reinterpret_cast<const int*>(stg + buf * STG + 128);
 #pragma unroll
         for (int i = 0; i < 2 * NPASS; ++i) {
             const int4 p4 = *reinterpret_cast<const int4*>(t2 + (lane >> 5) * 16 + 4 * i);
@@ -200,11 +201,14 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    Item it_cur{}, it_nx{}, it_pf{};
+    Item it_cur{}, it_nx{};
     take(it_cur);
-    prefetch(it_cur);
-    stage_in();
-    acc_cur = acc_nx;
+    prefetch(it_cur, 0);
+    glds_wait<0>();
+    stage_in(0);
+    lds_reads_done();
+    int cbuf = 0;   // staging buffer of the current item
+    float acc_cur = 0.f;
     // results of the previous item: stored right behind the next item's first DMA wait (vmcnt counts stores too, in order: a store
     // issued just in front of a wait stalls the wave for its whole round trip)
     f32x4 pend = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -244,19 +248,24 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     };
     issue(0, I0{}, I0{}, it_cur.b);
     issue(0, I0{}, I1{}, it_cur.b);
-    bool more = take(it_nx), has_pf = false;
-    if (more) prefetch(it_nx);
+    bool more = take(it_nx);
     for (;;) {
         const int b = it_cur.b, l00 = it_cur.l00, bn = it_nx.b;
+        const float* qs = stg + cbuf * STG;
+        const int* t2 = reinterpret_cast<const int*>(qs + 128);
         // ================================================================== K passes: logits of candidates 64p .. 64p+63
         f32x4 lg[NPASS];
         static_for<0, NPASS>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
             glds_wait<0>();
-            if constexpr (p == 0) flush();
+            if constexpr (p == 0) {
+                flush();
+                if (more) prefetch(it_nx, cbuf ^ 1);   // lands under this item's K pass and softmax; consumed at its chunk NV - 2
+                acc_cur = a.acc_in ? qs[192 + (lane & 31)] : 0.f;   // final[parent] of the item for d = lane % 32 (:277)
+            }
             f32x4 qa[8], kr[8];   // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row
 #pragma unroll
-            for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * QST + 4 * u);
+            for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * 32 + ((u ^ ((lane & 3) >> 1)) * 4));
 #pragma unroll
             for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ring) + rd[u]);
             lds_reads_done();
@@ -447,15 +456,11 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         static_for<0, NV>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            if constexpr (c == NV - 2) {
-                if (more) stage_in();   // every chunk of this item has been issued: the offsets become the next item's
-            }
-            // in flight behind chunk c: chunk c + 1 (or the next item's first K chunk) = 4 instructions
+            // in flight behind chunk c: chunk c + 1 (or the next item's first K chunk) = 4 instructions; the staging DMA of the next
+            // item is older than every V chunk, so it has landed behind the first of these waits
             if (c + 1 < NV || more) glds_wait<4>(); else glds_wait<0>();
             if constexpr (c == NV - 2) {
-                // the item after next: issued behind the wait, a whole chunk ahead of the next one
-                has_pf = more && take(it_pf);
-                if (has_pf) prefetch(it_pf);
+                if (more) stage_in(cbuf ^ 1);   // every chunk of this item has been issued: the offsets become the next item's
             }
             f32x4 pv[4];   // operand A of MFMA mm: P[child lane%4][parity lane/32][16 c + mm]
 #pragma unroll
@@ -488,8 +493,8 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             pend = tot; pend_acc = acc_cur; pend_b = b; pend_l00 = l00; have_pend = true;
         }
         if (!more) break;
-        acc_cur = acc_nx;
-        it_cur = it_nx; it_nx = it_pf; more = has_pf;
+        it_cur = it_nx; cbuf ^= 1;
+        more = take(it_nx);
     }
     glds_wait<0>();
     flush();
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
 
 template <int NPASS, bool EXACT>
 static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
-    constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 4 * 36 + 32);
+    constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 2 * 256);
     // persistent grid: exactly the workgroups that are resident at once
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
@@ -512,12 +517,28 @@ static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
     const int G = 8 / a.H;                                             // XCDs sharing a head split the pair's quads
     const long long per_pair = (a.nquads + G - 1) / G;
     long long wpx = (long long)res / 8 * 2;                            // resident waves per XCD
+    static int cu_count[CASMTR_MAX_DEVICES] = {0};
+    int ncu = 0;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return CASMTR_ERR_UNSUPPORTED;
+        ncu = __atomic_load_n(&cu_count[dev], __ATOMIC_RELAXED);
+        if (!ncu) {
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return CASMTR_ERR_UNSUPPORTED;
+            __atomic_store_n(&cu_count[dev], ncu, __ATOMIC_RELAXED);
+        }
+    }
+    const long long even = ncu >= 8 ? 2ll * (ncu / 8) : 2;             // one more workgroup (2 waves) on every CU of an XCD
     const char* ev = getenv("CASMTR_FQ_WAVES_PER_XCD");                // measurement knob (tools/fq_sweep.py)
     if (ev && atoi(ev) > 0) wpx = atoi(ev) < wpx ? atoi(ev) : wpx;
     else if (2ull * 2 * a.lq1 * 512 > 3ull << 20) {                    // two K + V slices against 3 of the L2's 4 MB
         long long rounds = (per_pair + wpx - 1) / wpx;
         if (rounds < 8) rounds = 8;
         wpx = (per_pair + rounds - 1) / rounds;
+        // ... and the same number of workgroups on every CU: the items are dealt out statically, so the CUs that hold one workgroup
+        // more run all their waves slower and finish last (round 4, 104x104, B = 8: 338 waves per XCD 226 us, 320 = 5 workgroups on
+        // each of the 32 CUs 193 us, 256 192 us, 352 221 us, 384 218 us)
+        if (wpx > even) wpx = wpx / even * even;
     }
     if (wpx > per_pair * a.B) wpx = per_pair * a.B;
     const long long blocks = (wpx + 1) / 2 * 8;
@@ -538,6 +559,10 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
         (long long)(h1 / 2) * (w1 / 2) * (w1 / 2) >= (1ll << 32))   // umulhi(p, ceil(2^32 / d)) == p / d needs p * d < 2^32 (p < lq1, d = w1 / 2)
         return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
+    {   // the staging DMA addresses q / parents / acc_in with 32-bit byte offsets from the tensor base
+        const long long lq0 = (long long)(h0 / 2) * (w0 / 2);
+        if ((long long)B * H * lq0 * 512 >= (1ll << 32) || (long long)B * H * lq0 * Kp * 4 >= (1ll << 32)) return CASMTR_ERR_UNSUPPORTED;
+    }
     FineQArgs a{};
     a.q = q; a.key = key; a.value = value; a.parents = parents; a.acc_in = acc_in; a.message = message; a.acc_out = acc_out;
     a.topk_tab = topk_tab; a.topk_score = topk_score; a.topk_idx = topk_idx; a.temp = temp; a.w_level = w_level; a.topk = topk;
