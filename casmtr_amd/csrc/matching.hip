@@ -446,8 +446,11 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     hipStream_t s = (hipStream_t)stream;
     DsWs w;
     ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S, 0);
-    hipError_t e = hipMemsetAsync(w.rbest, 0, (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)), s);
-    if (e != hipSuccess) return (int)e;
+    // a kernel, not hipMemsetAsync: inside a captured HIP graph (casmtr_amd/graph.py) a memset node is not reliably ordered against
+    // the kernels around it on this ROCm stack (replays faulted after tens of steps: counters read before they were cleared)
+    hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest,
+                       (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)) / sizeof(unsigned long long), (const int*)nullptr);
+    CASMTR_CHECK_LAUNCH();
     int rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
                              next_idx10, next_conf10, B, L, S, C, nullptr, s);
     if (rc) return rc;
@@ -473,8 +476,11 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     DsWs w;
     ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S, C);
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
-    hipError_t e = hipMemsetAsync(w.rbest, 0, (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)), s);
-    if (e != hipSuccess) return (int)e;
+    // a kernel, not hipMemsetAsync: inside a captured HIP graph (casmtr_amd/graph.py) a memset node is not reliably ordered against
+    // the kernels around it on this ROCm stack (replays faulted after tens of steps: counters read before they were cleared)
+    hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest,
+                       (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)) / sizeof(unsigned long long), (const int*)nullptr);
+    CASMTR_CHECK_LAUNCH();
     int rc;
     {
         ProfScope ps(CASMTR_PROF_DS_SPLIT, s);

@@ -525,3 +525,30 @@ def test_full_size_kernel_variants_agree(monkeypatch, env):
             assert torch.equal(ref[k], alt[k]), f"{k}: index output differs under {env}"
         else:
             assert ref[k].shape == alt[k].shape and float((ref[k] - alt[k]).abs().max()) <= TOL, f"{k} under {env}"
+
+
+def test_hip_graph_replay_equals_eager():
+    """casmtr_amd.graph.GraphedHotPath: a whole step captured into a HIP graph and replayed 40 times (lists read one step behind)
+    returns the eager step's match lists bit for bit -- guards the capture-safety of every launch on the path (no hidden
+    allocation, synchronisation or memset node: the dual-softmax workspace is cleared by a kernel for that reason)"""
+    from casmtr_amd.graph import GraphedHotPath
+    from casmtr_amd.pipeline import HotPath, HotPathConfig, make_synthetic_inputs
+    cfg = HotPathConfig(name="small", image_hw=(256, 320), coarse_layers=2)
+    model = HotPath(cfg).to(DEV)
+    inp = make_synthetic_inputs(cfg, 2, DEV, seed=7)
+    with torch.no_grad():
+        model.qta.weight.copy_(inp["weight"])
+    ref = model(inp)
+    ref = {k: ref[k].clone() for k in ("m_bids", "mkpts0", "mkpts1", "mconf")}
+    gs = GraphedHotPath(model, inp)
+    pend = None
+    for _ in range(40):
+        new = gs.enqueue()
+        if pend is not None:
+            o = gs.finalize(pend)
+            for k in ref:
+                assert torch.equal(o[k], ref[k]), k
+        pend = new
+    o = gs.finalize(pend)
+    assert all(torch.equal(o[k], ref[k]) for k in ref)
+    assert int(ref["m_bids"].numel()) > 0
