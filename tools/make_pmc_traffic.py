@@ -17,7 +17,7 @@ BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_k
               ("nchw_to_quads_kernel", "nchw_to_quads_kernel"),
               ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
               ("cascade_quad_kernel", "quad_attn_kernel<cascade>"),
-              ("coarse_fused_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
+              ("coarse_fused_kernel", "coarse_fused_kernel"), ("coarse_tile_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
               ("ds_gemm16_kernel", "ds_gemm_kernel"), ("ds_gemm_kernel<", "ds_gemm_kernel[exact fp32; in split mode: the guarded fallback launch]"),
               ("ds_sparse_kernel", "ds_conf_kernel"), ("ds_conf_kernel", "ds_conf_kernel[dense]"),
               ("ds_split_kernel", "ds_split_kernel"), ("ds_rownorm_kernel", "ds_split_kernel"), ("ds_fix_kernel", "ds_fix_kernel"),
