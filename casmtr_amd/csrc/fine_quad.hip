@@ -33,7 +33,7 @@
 // global_load_lds_dword into a double-buffered 1 KB staging area, issued at the START of the current item, consumed under its last
 // V chunks).  Round 3 fetched them with ordinary global loads into registers; the compiler cannot see the DMA instructions, so its
 // own `s_waitcnt vmcnt(0)` for those loads -- placed right behind them, where it copies the values into the loop-carried registers --
-// drained the whole DMA ring two or three times per item (profiles/r04_fine_quad_vmcnt.md).  Now the loop contains no
+// drained the whole DMA ring two or three times per item.  Now the loop contains no
 // compiler-visible vector load at all (tools/check_quad_isa.py checks that).
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Build-time guard for the quad-major LDS-DMA kernels (casmtr_amd/csrc/fine_quad.hip, cascade_quad.hip).  Their DMA chunks are
+"""Build-time guard for the LDS-DMA kernels with hand-counted waits (casmtr_amd/csrc/fine_quad.hip, cascade_quad.hip, coarse_tile.hip).  Their DMA chunks are
 issued from inline asm that (a) writes M0 without saving it and (b) is waited for with hand-counted `s_waitcnt vmcnt(N)`.  Both are
 only sound if the compiler
   * never touches M0 itself in these kernels (every M0 reference must sit inside an ;;#ASMSTART / ;;#ASMEND block), and
   * never spills (a scratch load / store between a DMA issue and its wait changes the vector-memory count the waits rely on).
-Compiles both files to gfx950 assembly and checks every template instance.  Exit status 0 = ok."""
+fine_quad.hip additionally promises that its loop contains NO compiler-visible vector load and no compiler-generated `vmcnt` wait
+(its front end stages the next item by DMA; an ordinary load would make the compiler drain the DMA ring with its own vmcnt(0)).
+coarse_tile.hip: the instances used by the shipped configs (EMAX <= 11) must not spill; its query loads are waited for in the prologue.
+Compiles the files to gfx950 assembly and checks every template instance.  Exit status 0 = ok."""
 import os
 import re
 import subprocess
@@ -12,7 +15,9 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = {"fine_quad.hip": ("fine_quad_kernel", 4), "cascade_quad.hip": ("cascade_quad_kernel", 2)}
+FILES = {"fine_quad.hip": ("fine_quad_kernel", 4), "cascade_quad.hip": ("cascade_quad_kernel", 2), "coarse_tile.hip": ("coarse_tile_kernel", 30)}
+NO_COMPILER_VMEM = {"fine_quad_kernel"}          # no vector load / vmcnt wait outside the inline-asm blocks
+SPILL_EXEMPT = re.compile(r"coarse_tile_kernelILi16E")   # S > 704 keys: 144 VGPRs at 3 waves per SIMD, spill-free today but not promised
 
 
 def check(asm_text, kernel, n_expected):
@@ -23,7 +28,7 @@ def check(asm_text, kernel, n_expected):
     for name in names:
         body = asm_text.split(name + ":", 1)[1].split(".Lfunc_end", 1)[0]
         lines = body.split("\n")
-        if any(re.match(r"\s*scratch_", l) for l in lines):
+        if any(re.match(r"\s*scratch_", l) for l in lines) and not SPILL_EXEMPT.search(name):
             problems.append(f"{name}: scratch instructions present (register spills)")
         in_asm = False
         ndma = 0
@@ -35,10 +40,12 @@ def check(asm_text, kernel, n_expected):
             code = l.split(";")[0]
             if re.search(r"\bm0\b", code) and not in_asm:
                 problems.append(f"{name}: compiler-generated M0 access: {code.strip()}")
-            if "global_load_lds_dwordx4" in code:
+            if "global_load_lds_dword" in code:
                 ndma += 1
                 if not in_asm:
                     problems.append(f"{name}: LDS-DMA outside inline asm")
+            elif kernel in NO_COMPILER_VMEM and not in_asm and (re.match(r"\s*(global|buffer|flat)_load", code) or "vmcnt" in code):
+                problems.append(f"{name}: compiler-visible vector load / vmcnt wait in a hand-counted DMA kernel: {code.strip()}")
         if ndma == 0:
             problems.append(f"{name}: no LDS-DMA instructions found")
         meta = asm_text.split(f".name:           {name}", 1)
