@@ -96,7 +96,8 @@ __device__ __forceinline__ void merge_round(unsigned (&s)[8], bool odd) {
     bitonic8_desc(s);
 }
 
-template <int NPASS, bool EXACT>   // EXACT: the level feeds a finer one (top-k requested): bit-exact sequential d-chain
+template <int NPASS, bool EXACT, bool FULL>   // EXACT: the level feeds a finer one (top-k requested): bit-exact sequential d-chain;
+                                              // FULL: the lists have exactly 64 * NPASS candidates (every shipped config): no per-element bound test
 __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(const FineQArgs a) {
     constexpr int KMAX = 64 * NPASS;
     constexpr int E = KMAX / 16;          // elements per lane in the series-per-row phase
@@ -328,14 +329,14 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
                 unsigned lm = 0;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    xk[e] = (j * E + e < K) ? f2ord(lv[e]) : 0u;
+                    xk[e] = (FULL || j * E + e < K) ? f2ord(lv[e]) : 0u;
                     lm = max(lm, xk[e]);
                 }
                 m = ord2f(row16_max_u32(lm));
             } else {   // no selection: the maximum only centres the exponentials
                 float fm = -3.0e38f;
 #pragma unroll
-                for (int e = 0; e < E; ++e) fm = (j * E + e < K) ? fmaxf(fm, lv[e]) : fm;
+                for (int e = 0; e < E; ++e) fm = (FULL || j * E + e < K) ? fmaxf(fm, lv[e]) : fm;
                 fm = fmaxf(fm, dpp_f32<0xB1>(fm));
                 fm = fmaxf(fm, dpp_f32<0x4E>(fm));
                 fm = fmaxf(fm, dpp_f32<0x141>(fm));
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                ps[e] = (j * E + e < K) ? __expf(lv[e] - m) : 0.f;
+                ps[e] = (FULL || j * E + e < K) ? __expf(lv[e] - m) : 0.f;
                 sum += ps[e];
             }
             sum = __builtin_amdgcn_rcpf(row16_sum_f32(sum));   // 1 ulp: the probabilities carry a 1e-4 tolerance, no index depends on them
@@ -500,13 +501,13 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     flush();
 }
 
-template <int NPASS, bool EXACT>
+template <int NPASS, bool EXACT, bool FULL>
 static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
     constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 2 * 256);
     // persistent grid: exactly the workgroups that are resident at once
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
-    if (const int r = resident_workgroups(resident, fine_quad_kernel<NPASS, EXACT>, 128, lds, &res)) return r;
+    if (const int r = resident_workgroups(resident, fine_quad_kernel<NPASS, EXACT, FULL>, 128, lds, &res)) return r;
     // Waves per XCD.  An XCD walks the pairs one after the other, its 4 MB L2 holding one (pair, head) slice of K and V at a time.
     // While the first waves are already on the next pair and the last ones still on this one, two slices compete for the cache; the
     // share of the time spent like that is (waves in flight) / (items per pair).  Measured on the finest CasMTR-4c level (2.8 MB
@@ -544,7 +545,7 @@ static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
     const long long blocks = (wpx + 1) / 2 * 8;
     if (getenv("CASMTR_FQ_DEBUG")) fprintf(stderr, "fine_quad<%d,%d>: %zu B LDS per workgroup, %d resident workgroups, launching %lld\n", NPASS, (int)EXACT, lds, res, blocks);
     ProfScope ps(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, s);
-    hipLaunchKernelGGL((fine_quad_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(128), lds, s, a);
+    hipLaunchKernelGGL((fine_quad_kernel<NPASS, EXACT, FULL>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -571,6 +572,11 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
     a.div_magic = d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u;
     { const char* ev = getenv("CASMTR_FQ_FLAGS"); a.xflags = ev ? atoi(ev) : 0; }
     hipStream_t s = (hipStream_t)stream;
-    if (topk > 0) return K <= 64 ? launch_fine_quad<1, true>(a, s) : launch_fine_quad<2, true>(a, s);
-    return K <= 64 ? launch_fine_quad<1, false>(a, s) : launch_fine_quad<2, false>(a, s);
+    const bool full = K == 64 || K == 128;
+    if (topk > 0) {
+        if (K <= 64) return full ? launch_fine_quad<1, true, true>(a, s) : launch_fine_quad<1, true, false>(a, s);
+        return full ? launch_fine_quad<2, true, true>(a, s) : launch_fine_quad<2, true, false>(a, s);
+    }
+    if (K <= 64) return full ? launch_fine_quad<1, false, true>(a, s) : launch_fine_quad<1, false, false>(a, s);
+    return full ? launch_fine_quad<2, false, true>(a, s) : launch_fine_quad<2, false, false>(a, s);
 }
