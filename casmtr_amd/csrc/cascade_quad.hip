@@ -13,7 +13,14 @@
 // No index depends on these logits (upsampled_idx is the window list itself), so the d-sum uses four interleaved partial chains
 // and the result carries the 1e-4 softmax tolerance; rel_pos (indoor model) is added to the logits as in :438-441.
 //
-// Pipeline per sub-item (one head of one quad pair; XCD x serves head x % H): fine_quad.hip's two-pass schedule -- K chunks (4 KB =
+// Round 4: a wave can walk several heads of a sub-item before it moves on (unit = (sub-item, head); CASMTR_CQ_HEADS_PER_WAVE).  The window
+// lists are shared by the heads (:419-429), so the per-item front end -- 2 x 25 int64 positions, the regularity test, the sharing decision,
+// masks, 16 DMA offsets -- then runs once per sub-item instead of once per (sub-item, head): about a quarter of the kernel's VALU / SALU
+// work at H = 4.  Only the queries differ between the heads of a sub-item: they arrive by one LDS-DMA instruction per unit (both quads'
+// 512 bytes) in a double-buffered staging area.  It pays on isolated launches with smooth windows and not inside the real step (see
+// the launcher), so the default stays one head per wave = XCD <-> head.
+//
+// Pipeline per unit (one head of one quad pair): fine_quad.hip's two-pass schedule -- K chunks (4 KB =
 // 8 cells) through a two-slot ring, lane <-> candidate v_mfma_f32_4x4x1 logits for slot 0 and slot 1 against the SAME staged rows,
 // softmax with one series per 16-lane DPP row, V chunks with the probabilities as operand A, next sub-item's K under the last V chunks.
 #include <stdio.h>
@@ -32,31 +39,34 @@ struct CasQArgs {
     float* message;        // [B,L,H*32]
     float temp;
     int B, h0, w0, h1, w1, H, nquads, lq1, npr, nitems;   // npr = pair items per quad row, nitems = pair items per image pair
+    int hw;                // heads a wave walks per sub-item (divides H): the XCDs split into H / hw head groups x 8 hw / H item chunks
     int colmajor;          // item order inside an XCD's chunk: 1 = down the columns of quad pairs (consecutive items of a wave's neighbours
                            // share 4 of their 5 window rows), 0 = along the rows
 };
 
-struct Sub {   // one pipeline unit: the candidate rows of `ncells` cells against nq query quads (all wave-uniform)
+struct Sub {   // one sub-item: the candidate rows of `ncells` cells against nq query quads (all wave-uniform)
     int b, l00_0, nq, ncells;   // slot 1's quad is the right-hand neighbour: first token l00_0 + 2
     unsigned mask0, mask1;   // bit e: cell e belongs to slot 0's / slot 1's window
+    int quadA, hasB, qslot;  // the item's left quad, whether it has a right neighbour, staging slot of query slot 0 (1: the right quad runs alone)
 };
 
 template <bool HAS_REL>
 __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(const CasQArgs a) {
     constexpr int KW = 25, KS = 128 + 4, PST = 64 + 4, SLOT_FLOATS = 8 * PST;   // per query slot: P[child][parity][64] / logits [4][KS]
     static_assert(SLOT_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
-    constexpr int QST = 36;               // query row stride: the 4 children's rows (lane % 4 broadcast reads) in different banks
-    constexpr int WAVE_FLOATS = 2048 + 2 * SLOT_FLOATS + 2 * 4 * QST + 32;
+    constexpr int QBUF = 256;             // one unit's queries: [2 query slots][4 children][32 d], 16-byte units XOR-swizzled by (child >> 1)
+    constexpr int WAVE_FLOATS = 2048 + 2 * SLOT_FLOATS + 2 * QBUF + 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* ring = smem + wave * WAVE_FLOATS;                // 2 slots x 32 rows x 128 B (XOR-swizzled 16-byte units)
     float* Pld = ring + 2048;                               // [2 query slots][SLOT_FLOATS]
-    float* qs = Pld + 2 * SLOT_FLOATS;                      // [2 query slots][4 children][QST]
-    int* t2 = reinterpret_cast<int*>(qs + 2 * 4 * QST);             // t2[parity * 16 + j] = cell 2j + parity
+    float* qst = Pld + 2 * SLOT_FLOATS;                     // [2 units][QBUF]: queries of the current / the next unit (LDS-DMA)
+    int* t2 = reinterpret_cast<int*>(qst + 2 * QBUF);               // t2[parity * 16 + j] = cell 2j + parity
     const int H = a.H, HD = H * 32, L = a.h0 * a.w0, wq = a.w0 >> 1, Lq = a.nquads, h1p = a.h1 >> 1, w1p = a.w1 >> 1;
-    // ---- work list: XCD x -> head x % H; the 8 / H XCDs sharing a head split every image pair's quad pairs into contiguous chunks
-    const int xcd = blockIdx.x & 7, h = xcd % H, G = 8 / H, g = xcd / H;
+    // ---- work list: XCD x -> head group x % (H / hw) (heads h0 .. h0 + hw - 1), the XCDs sharing a group split every image pair's quad
+    //      pairs into contiguous chunks; a wave walks the hw heads of a sub-item before it moves on
+    const int HW = a.hw, ngrp = H / HW, xcd = blockIdx.x & 7, h0 = (xcd % ngrp) * HW, G = 8 / ngrp, g = xcd / ngrp;
     const int chunk = (a.nitems + G - 1) / G, cnt = min(chunk, a.nitems - g * chunk);
     const int total = cnt > 0 ? a.B * cnt : 0, stride = (gridDim.x >> 3) * 2;
     int t = (blockIdx.x >> 3) * 2 + wave;
@@ -76,13 +86,15 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
 #pragma unroll
     for (int x = 0; x < 8; ++x) va[x] = (unsigned)((lane >> 5) * 128 + ((((lane & 31) >> 2) ^ x) * 16) + (lane & 3) * 4);
     const int paoff = ((lane & 3) * 2 + (lane >> 5)) * PST;   // operand A of the V chunks: P[child lane%4][parity lane/32][.]
-    const size_t pair_pitch = (size_t)H * a.lq1 * 128;
-    const float* const k0 = a.key + (size_t)h * a.lq1 * 128 - 768;     // this head's slice of image pair 0, 3072 bytes low
-    const float* const v0 = a.value + (size_t)h * a.lq1 * 128 - 768;
+    const size_t head_pitch = (size_t)a.lq1 * 128;                      // floats between two (pair, head) slices
+    const float* const k0 = a.key - 768;                               // 3072 bytes low
+    const float* const v0 = a.value - 768;
+    const unsigned qst_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(qst));
+    // query staging: lane l -> slot l / 32, child (l / 8) % 4, physical unit l % 8 <- logical unit (l % 8) ^ (child >> 1)
+    const unsigned qsrc = (unsigned)(((lane >> 3) & 3) * 128 + (((lane & 7) ^ (((lane >> 3) & 3) >> 1)) * 16));
 
     // ---- item-level prefetch registers: window positions (lane e < 25: quad A, lane 32 + e: quad B) and queries (halves likewise)
     int pf_r = 0, pf_c = 0;
-    f32x4 pf_q = (f32x4){0.f, 0.f, 0.f, 0.f};
     int pf_b = 0, pf_quadA = 0, pf_l00A = 0;
     bool pf_hasB = false;
     bool regs_full = false, pendB = false;
@@ -97,7 +109,6 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
                 const longlong2 rc = *reinterpret_cast<const longlong2*>(a.tp + (((size_t)b * Lq + quad) * KW + e) * 2);
                 pf_r = (int)rc.x; pf_c = (int)rc.y;
             }
-            pf_q = *reinterpret_cast<const f32x4*>(a.q + (((size_t)b * H + h) * Lq + quad) * 128 + e * 4);
         }
         regs_full = true;
     };
@@ -108,13 +119,11 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
         const int e = lane & 31;
         const int cl = min(max(pf_r, 0), h1p - 1) * w1p + min(max(pf_c, 0), w1p - 1);   // this lane's cell (valid for e < 25)
         int cellv;
-        bool q_lo = true;   // which half's queries go to slot 0
         if (pendB) {        // second half of a pair that could not share: quad B alone
             const int last = __builtin_amdgcn_readlane(cl, 32 + KW - 1);
             cellv = e < KW ? cl : last;
             if (lane >= 32) t2[(e & 1) * 16 + (e >> 1)] = cellv;
-            sub_nx = Sub{pf_b, pf_l00A + 2, 1, KW, (1u << KW) - 1u, 0u};
-            q_lo = false;
+            sub_nx = Sub{pf_b, pf_l00A + 2, 1, KW, (1u << KW) - 1u, 0u, pf_quadA, 1, 1};
             pendB = false; regs_full = false;
         } else {
             const int oyA = __builtin_amdgcn_readlane(pf_r, 0), oxA = __builtin_amdgcn_readlane(pf_c, 0);
@@ -133,19 +142,16 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
                 unsigned mA = 0, mB = 0;
 #pragma unroll
                 for (int r = 0; r < 5; ++r) { mA |= 0x1Fu << (bw * r + (oxA - bx0)); mB |= 0x1Fu << (bw * r + (oxB - bx0)); }
-                sub_nx = Sub{pf_b, pf_l00A, 2, nc, mA, mB};
+                sub_nx = Sub{pf_b, pf_l00A, 2, nc, mA, mB, pf_quadA, 1, 0};
                 regs_full = false;
             } else {                                                   // quad A alone now; quad B (if any) as the next sub-item
                 const int last = __builtin_amdgcn_readlane(cl, KW - 1);
                 cellv = e < KW ? cl : last;
                 if (lane < 32) t2[(e & 1) * 16 + (e >> 1)] = cellv;
-                sub_nx = Sub{pf_b, pf_l00A, 1, KW, (1u << KW) - 1u, 0u};
+                sub_nx = Sub{pf_b, pf_l00A, 1, KW, (1u << KW) - 1u, 0u, pf_quadA, (int)pf_hasB, 0};
                 pendB = pf_hasB; regs_full = pf_hasB;
             }
         }
-        // queries: slot 0 <- the lower half's (or quad B's when it runs alone), slot 1 <- the upper half's
-        if (sub_nx.nq == 2) *reinterpret_cast<f32x4*>(qs + (lane >> 3) * QST + (lane & 7) * 4) = pf_q;
-        else if ((lane < 32) == q_lo) *reinterpret_cast<f32x4*>(qs + (e >> 3) * QST + (e & 7) * 4) = pf_q;
         wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -157,10 +163,11 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
         }
     };
     // chunk c (cells 8c .. 8c+7) of pass p of K (isv = 0) or V (isv = 1) -> ring slot c; the last chunk (cells 24 ..) is short
-    auto issue = [&](int isv, auto pc, auto cc, const Sub& s) {
+    auto issue = [&](int isv, auto pc, auto cc, const Sub& s, int hh) {
         constexpr int p = decltype(pc)::value, c = decltype(cc)::value;
         const int sb = __builtin_amdgcn_readfirstlane(s.b);               // wave-uniform by construction; tell the compiler
-        const float* base = (isv ? v0 : k0) + (size_t)sb * pair_pitch;
+        const int hu = __builtin_amdgcn_readfirstlane(hh);
+        const float* base = (isv ? v0 : k0) + ((size_t)sb * H + hu) * head_pitch;
         const unsigned dst = ring_lds + (unsigned)(c * 4096);
         if constexpr (p == 1 && c == 1) {
             const int n3 = __builtin_amdgcn_readfirstlane((s.ncells - 24 + 1) >> 1);
@@ -175,14 +182,24 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
+    // the queries of both quads of item (b, quadA) for head hh -> staging buffer `buf` (one instruction: lanes 0-31 the left quad,
+    // 32-63 the right one, or the left one again when there is none)
+    auto issue_q = [&](int b, int quadA, int hasB, int hh, int buf) {
+        const int row0 = __builtin_amdgcn_readfirstlane((b * H + hh) * Lq + quadA), hb = __builtin_amdgcn_readfirstlane(hasB);
+        const unsigned off = (unsigned)((row0 + ((lane >> 5) & hb)) * 512) + qsrc + 3072u;
+        glds_chunk1(a.q - 768, off, qst_lds + (unsigned)(buf * QBUF * 4));
+    };
     prefetch(t);
     t += stride;
     stage_in();
     sub_cur = sub_nx;
     if (!regs_full && t < total) { prefetch(t); t += stride; }
-    // results of the previous sub-item: stored right behind the next one's first DMA wait
+    int hcur = h0, ubuf = 0;   // head of the current unit, its query staging buffer
+    issue_q(sub_cur.b, sub_cur.quadA, sub_cur.hasB, h0, 0);
+    // results of the previous unit: stored right behind the next one's first DMA wait
     f32x4 pend[2];
     Sub pend_sub{};
+    int pend_h = 0;
     bool have_pend = false;
     auto flush = [&]() {
         if (have_pend) {
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             for (int sl = 0; sl < 2; ++sl) {
                 if (sl < pend_sub.nq) {
                     const float vA = hi ? pend[sl][2] : pend[sl][0], vB = hi ? pend[sl][3] : pend[sl][1];
-                    const size_t o = ((size_t)pend_sub.b * L + (pend_sub.l00_0 + 2 * sl) + hi * a.w0) * HD + h * 32 + (lane & 31);
+                    const size_t o = ((size_t)pend_sub.b * L + (pend_sub.l00_0 + 2 * sl) + hi * a.w0) * HD + pend_h * 32 + (lane & 31);
                     a.message[o] = vA;
                     a.message[o + HD] = vB;
                 }
@@ -199,11 +216,17 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
         }
         have_pend = false;
     };
-    issue(0, I0{}, I0{}, sub_cur);
-    issue(0, I0{}, I1{}, sub_cur);
-    bool more = regs_full || pendB;   // another sub-item follows
+    issue(0, I0{}, I0{}, sub_cur, h0);
+    issue(0, I0{}, I1{}, sub_cur, h0);
     for (;;) {
         const Sub s = sub_cur;
+        const int h = hcur;
+        const bool same = h + 1 < h0 + HW;                 // the next unit is the next head of this sub-item: same cells, masks, offsets
+        const bool more_sub = regs_full || pendB;          // another sub-item follows (its item's identity is in the prefetch registers)
+        const bool more = same || more_sub;
+        const int hn = same ? h + 1 : h0;
+        const float* qcur = qst + ubuf * QBUF + s.qslot * 128 + (lane & 3) * 32;
+        const int qsw = (lane & 3) >> 1;
         const int n3 = (s.ncells - 24 + 1) >> 1;          // DMA instructions of the short last chunk
         const int nrow3 = 4 * s.ncells - 96;              // its valid rows
         // ================================================================== K passes: logits of rows 64p .. 64p+63 for both query slots
@@ -213,6 +236,9 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             glds_wait<0>();
             if constexpr (p == 0) {
                 flush();
+                // the next unit's queries: a whole unit ahead of their use (they come from HBM; everything issued later waits behind them)
+                if (same) issue_q(s.b, s.quadA, s.hasB, hn, ubuf ^ 1);
+                else if (more_sub) issue_q(pf_b, pf_quadA, (int)pf_hasB, h0, ubuf ^ 1);
                 if constexpr (HAS_REL) {   // :438-441; candidate index within the quad's own list = rank of the cell in its window * 4 + child
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl)
@@ -235,11 +261,11 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ring) + rd[u]);
             lds_reads_done();
             if constexpr (p == 0) {          // the ring is free again: K pass 1
-                issue(0, I1{}, I0{}, s);
-                issue(0, I1{}, I1{}, s);
+                issue(0, I1{}, I0{}, s, h);
+                issue(0, I1{}, I1{}, s, h);
             } else {                         // ... or the first two chunks of V
-                issue(1, I0{}, I0{}, s);
-                issue(1, I0{}, I1{}, s);
+                issue(1, I0{}, I0{}, s, h);
+                issue(1, I0{}, I1{}, s, h);
             }
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
                 for (int hf = 0; hf < 2; ++hf) {   // operand A in two halves of 16 d (16 VGPRs instead of 32): lane l holds q[slot][child l%4][d]
                     f32x4 qa[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (sl * 4 + (lane & 3)) * QST + 16 * hf + 4 * u);
+                    for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qcur + sl * 128 + (((4 * hf + u) ^ qsw) * 4));
                     lds_reads_done();
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -318,14 +344,14 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
         static_for<0, 4>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             if constexpr (c == 2) {
-                if (more) stage_in();   // every chunk of this sub-item has been issued: the offsets become the next one's
+                if (!same && more_sub) stage_in();   // last head, every chunk issued: the offsets become the next sub-item's
             }
             // in flight behind chunk c: chunk c + 1 (the short one behind chunk 2), or the next sub-item's first K chunk
             if constexpr (c == 2) glds_wait_dyn(n3);
             else if constexpr (c == 3) { if (more) glds_wait<4>(); else glds_wait<0>(); }
             else glds_wait<4>();
             if constexpr (c == 2) {
-                if (more && !regs_full && t < total) { prefetch(t); t += stride; }   // issued behind the wait
+                if (!same && more_sub && !regs_full && t < total) { prefetch(t); t += stride; }   // issued behind the wait
             }
             const int nmm = c < 3 ? 16 : (nrow3 >> 1);   // valid row pairs of this chunk
             float vb[16];
@@ -341,10 +367,10 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
                 }
             lds_reads_done();
             // the slot is free: the next V chunk, or the next sub-item's K pass 0
-            if constexpr (c == 0) issue(1, I1{}, I0{}, s);
-            else if constexpr (c == 1) issue(1, I1{}, I1{}, s);
-            else if constexpr (c == 2) { if (more) issue(0, I0{}, I0{}, sub_nx); }
-            else { if (more) issue(0, I0{}, I1{}, sub_nx); }
+            if constexpr (c == 0) issue(1, I1{}, I0{}, s, h);
+            else if constexpr (c == 1) issue(1, I1{}, I1{}, s, h);
+            else if constexpr (c == 2) { if (more) issue(0, I0{}, I0{}, same ? s : sub_nx, hn); }
+            else { if (more) issue(0, I0{}, I1{}, same ? s : sub_nx, hn); }
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 if (sl < s.nq) {
@@ -377,10 +403,10 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
                 pend[sl] = tot;
             }
         }
-        pend_sub = s; have_pend = true;
+        pend_sub = s; pend_h = h; have_pend = true;
         if (!more) break;
-        sub_cur = sub_nx;
-        more = regs_full || pendB;
+        if (!same) sub_cur = sub_nx;
+        hcur = hn; ubuf ^= 1;
     }
     glds_wait<0>();
     flush();
@@ -388,11 +414,11 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
 
 template <bool HAS_REL>
 static int launch_cas_quad(const CasQArgs& a, hipStream_t s) {
-    constexpr size_t lds = 2 * sizeof(float) * (2048 + 2 * 8 * 68 + 2 * 4 * 36 + 32);
+    constexpr size_t lds = 2 * sizeof(float) * (2048 + 2 * 8 * 68 + 2 * 256 + 32);
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
     if (const int r = resident_workgroups(resident, cascade_quad_kernel<HAS_REL>, 128, lds, &res)) return r;
-    const int G = 8 / a.H;
+    const int G = 8 / (a.H / a.hw);
     const long long per_pair = (a.nitems + G - 1) / G;
     long long wpx = (long long)res / 8 * 2;                            // resident waves per XCD
     const char* ev = getenv("CASMTR_CQ_WAVES_PER_XCD");                // measurement knob
@@ -418,5 +444,13 @@ extern "C" int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, co
     a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.H = nhead; a.nquads = (h0 / 2) * (w0 / 2); a.lq1 = (h1 / 2) * (w1 / 2);
     a.npr = (w0 / 2 + 1) / 2; a.nitems = (h0 / 2) * a.npr;
     { const char* ev = getenv("CASMTR_CQ_ORDER"); a.colmajor = !(ev && ev[0] == 'r'); }
+    // heads per wave: the front end (positions, sharing decision, masks, DMA offsets) is amortised over them, but an XCD's L2 then
+    // holds that many heads' window neighbourhoods at once (~1.3 MB each at 208 x 208 with 320 waves per XCD).  Measured (round 4):
+    // isolated launches on perfectly smooth windows 519 -> 466 us with all 4 heads per wave; inside the bench step (windows from the
+    // real coarse matches, 8-15 % of them incoherent) 12.80 / 12.81 / 12.85 ms per step at 1 / 2 / 4 heads per wave, CasMTR-2c 21.4 /
+    // 22.0 / 22.0 ms: there the kernel is bound by its memory traffic, not by its instruction stream.  Default: one head per wave
+    // (XCD <-> head, the round-3 mapping).
+    a.hw = 1;
+    { const char* ev = getenv("CASMTR_CQ_HEADS_PER_WAVE"); const int v = ev ? atoi(ev) : 0; if (v >= 1 && v <= nhead && nhead % v == 0 && (8 % (nhead / v)) == 0) a.hw = v; }
     return rel_pos ? launch_cas_quad<true>(a, (hipStream_t)stream) : launch_cas_quad<false>(a, (hipStream_t)stream);
 }
