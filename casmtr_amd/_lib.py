@@ -59,6 +59,7 @@ SIGNATURES = {
     "casmtr_prof_enable": (None, [_I]),
     "casmtr_debug_set": (None, [_I]),
     "casmtr_prof_enable_only": (_I, [_I]),
+    "casmtr_prof_reserve": (_I, [_I]),
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
 }
@@ -73,6 +74,11 @@ def prof_enable_only(name: str):
     """Time only the kernel called `name` (as reported by prof_read)."""
     ids = {lib().casmtr_prof_name(i).decode(): i for i in range(PROF_COUNT)}
     check(lib().casmtr_prof_enable_only(ids[name]), "prof_enable_only")
+
+
+def prof_reserve(pairs: int):
+    """create the event pairs a timed region will need up front"""
+    check(lib().casmtr_prof_reserve(int(pairs)), "prof_reserve")
 
 
 def prof_read():

@@ -60,6 +60,18 @@ extern "C" int casmtr_prof_enable_only(int id) {
     return 0;
 }
 
+// Create `pairs` event pairs now (e.g. launches per step x timed steps) so that no hipEventCreate falls into a timed region.
+extern "C" int casmtr_prof_reserve(int pairs) {
+    for (int i = (int)g_free.size(); i < pairs; ++i) {
+        Pair p;
+        hipError_t e = hipEventCreate(&p.a);
+        if (e == hipSuccess) e = hipEventCreate(&p.b);
+        if (e != hipSuccess) return (int)e;
+        g_free.push_back(p);
+    }
+    return 0;
+}
+
 extern "C" int casmtr_prof_read(int id, double* total_ms, int* count) {
     if (id < 0 || id >= CASMTR_PROF_COUNT) return 1;
     double tot = 0.0;

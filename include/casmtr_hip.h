@@ -288,6 +288,8 @@ void casmtr_prof_enable(int on);
 void casmtr_debug_set(int flags);
 /* fresh collection that times ONLY kernel `id` (two event records per launch of that kernel, none for the others) */
 int casmtr_prof_enable_only(int id);
+/* create `pairs` event pairs now, so that no hipEventCreate falls into a timed region (bench.py: launches per step x timed steps) */
+int casmtr_prof_reserve(int pairs);
 int casmtr_prof_read(int id, double* total_ms, int* count);
 const char* casmtr_prof_name(int id);
 
