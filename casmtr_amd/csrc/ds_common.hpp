@@ -226,8 +226,8 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
 }
 
 // ds_split.hip
-int ds_split_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
-                    hipStream_t s);
+int ds_split_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L, int S,
+                    int C, float temperature, int recip, hipStream_t s);
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s);
 int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, hipStream_t s);
 int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,

@@ -28,8 +28,10 @@ namespace casmtr {
 //   img[b][rb][ks = c/32][kg = (c/8)%4][part hi/lo][row 128][8 f16]   -- 16 KB per (row block, k-stage), every 1 KB of it one
 // wave-instruction of the GEMM's LDS-DMA and, inside a kg plane, the lane-linear 16-B runs its ds_read_b128 fragment loads want.
 // (1) one wave per row: exponent of the row maximum, epilogue factor, row norm, batch maximum of the norms
-__global__ __launch_bounds__(256) void ds_rownorm_kernel(const float* __restrict__ f, int N, int C, float inv_sqrtC, float k0,
-                                                         int* __restrict__ ex, float* __restrict__ fac, float* __restrict__ nrm, int Np) {
+//     The factor carries the padding mask in its SIGN (negative = masked row): the GEMM epilogues read it from there.
+__global__ __launch_bounds__(256) void ds_rownorm_kernel(const float* __restrict__ f, const uint8_t* __restrict__ mask, int N, int C,
+                                                         float inv_sqrtC, float k0, int* __restrict__ ex, float* __restrict__ fac,
+                                                         float* __restrict__ nrm, int Np) {
     const int lane = threadIdx.x & 63;
     const int gi = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;   // row of the padded range [0, Np)
     if (gi >= Np) return;
@@ -50,7 +52,8 @@ __global__ __launch_bounds__(256) void ds_rownorm_kernel(const float* __restrict
     const float nr = gi < N ? sqrtf(ss) * inv_sqrtC * 1.001f : 0.f;
     if (lane == 0) {
         ex[(size_t)b * Np + gi] = e;
-        fac[(size_t)b * Np + gi] = gi < N ? ldexpf(k0, e) : 0.f;
+        const float fv = gi < N ? ldexpf(k0, e) : 0.f;
+        fac[(size_t)b * Np + gi] = (mask && gi < N && mask[(size_t)b * N + gi] == 0) ? -fv : fv;
         nrm[(size_t)b * Np + gi] = nr;
     }
 }
@@ -100,14 +103,14 @@ __global__ __launch_bounds__(256) void ds_split_kernel(const float* __restrict__
     }
 }
 
-int ds_split_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
-                    hipStream_t s) {
+int ds_split_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L, int S,
+                    int C, float temperature, int recip, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C);
     const float k0 = (float)(1.0 / ((double)C * (double)temperature));
     (void)recip;   // the operand pre-scaling mode only matters to the exact chain (ds_fix_kernel)
-    hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NIB * 32, B), dim3(256), 0, s, feat0, L, C, 1.0f / sqrtC, k0, w.exA, w.fa, w.na, NIB * 128);
-    hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NJB * 32, B), dim3(256), 0, s, feat1, S, C, 1.0f / sqrtC, 1.0f, w.exB, w.fb, w.nb, NJB * 128);
+    hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NIB * 32, B), dim3(256), 0, s, feat0, mask0, L, C, 1.0f / sqrtC, k0, w.exA, w.fa, w.na, NIB * 128);
+    hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NJB * 32, B), dim3(256), 0, s, feat1, mask1, S, C, 1.0f / sqrtC, 1.0f, w.exB, w.fb, w.nb, NJB * 128);
     hipLaunchKernelGGL(ds_nmax_kernel, dim3(B, 2), dim3(256), 0, s, w.na, w.nb, NIB * 128, NJB * 128, w.namax, w.nbmax);
     hipLaunchKernelGGL(ds_split_kernel, dim3(NIB, B, (C + 63) / 64), dim3(256), 0, s, feat0, L, C, w.exA, w.imgA, NIB);
     hipLaunchKernelGGL(ds_split_kernel, dim3(NJB, B, (C + 63) / 64), dim3(256), 0, s, feat1, S, C, w.exB, w.imgB, NJB);
@@ -270,13 +273,15 @@ __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* sc
 #define DS16_STAGE 16384
 #define DS16_LDS (4 * 32 * 65 * 4 + 2 * 2 * 128 * 3 * 4 + 2 * 128 * 4)   // epilogue scratch (aliases the stages; the interior-tile
                                                                           // layout 4*32*68 + 2*2*128*2 floats is 512 B smaller) + factors
+#define DS16_LDS3 (3 * DS16_STAGE + 2 * 128 * 4)                          // three operand stages (prefetch distance 2) + factors
+template <int NSTG>   // operand stages in LDS: 2 (prefetch distance 1, 40 KB) or 3 (distance 2, 49 KB; still 3 workgroups per CU)
 __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
                                                            float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
     char* lds = reinterpret_cast<char*>(smem);
-    float* facA = smem + (DS16_LDS - 2 * 128 * 4) / 4;
+    float* facA = smem + ((NSTG == 3 ? DS16_LDS3 : DS16_LDS) - 2 * 128 * 4) / 4;
     float* facB = facA + 128;
     const int NSJ = (NJB + 7) >> 3;
     const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
@@ -290,14 +295,14 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     bool masked = false;
     if (tid < 128) {
         const int gi = tI * DS_BM + tid;
-        const float f = fa[((size_t)b * NIB + tI) * 128 + tid];
-        masked = mask0 && gi < L && mask0[(size_t)b * L + gi] == 0;
-        facA[tid] = masked ? -f : f;
+        const float f = fa[((size_t)b * NIB + tI) * 128 + tid];   // sign = padding mask (ds_rownorm_kernel)
+        masked = mask0 && gi < L && f < 0.f;
+        facA[tid] = f;
     } else {
         const int gj = tJ * DS_BN + tid - 128;
         const float f = fb[((size_t)b * NJB + tJ) * 128 + tid - 128];
-        masked = mask0 && gj < S && mask1[(size_t)b * S + gj] == 0;
-        facB[tid - 128] = masked ? -f : f;
+        masked = mask0 && gj < S && f < 0.f;
+        facB[tid - 128] = f;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -313,17 +318,35 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     const int any_masked = __syncthreads_or(masked);   // (barrier: the factor loads above have completed before any DMA is outstanding)
     glds_2k(a_src, voff, lds0);
     glds_2k(b_src, voff, lds0 + 8192);
+    if (NSTG == 3 && KS > 1) {
+        glds_2k(a_src + 8192, voff, lds0 + DS16_STAGE);
+        glds_2k(b_src + 8192, voff, lds0 + DS16_STAGE + 8192);
+    }
     const int hi = lane >> 5, ln = lane & 31;
     // fragment (ti, part): plane (kg = hi, part), row wr*64 + ti*32 + ln
     const char* fa_base = lds + (hi * 2) * 2048 + (wr * 64 + ln) * 16;
     const char* fb_base = lds + 8192 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
+    int buf = 0;
     for (int ks = 0; ks < KS; ++ks) {
-        glds_wait<0>();
-        __syncthreads();   // stage ks has landed for every wave; everyone is done reading the other buffer
-        const int buf = ks & 1;
-        if (ks + 1 < KS) {
-            glds_2k(a_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE));
-            glds_2k(b_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE) + 8192);
+        if (NSTG == 3) {
+            // stage ks has landed when only stage ks + 1 (4 instructions) is still in flight.  No __syncthreads here: its
+            // s_waitcnt vmcnt(0) would drain the stage that was just prefetched
+            if (ks + 1 < KS) glds_wait<4>(); else glds_wait<0>();
+            lds_reads_done();
+            __builtin_amdgcn_s_barrier();   // everyone's share of stage ks has landed; everyone is done reading the buffer that is refilled next
+            asm volatile("" ::: "memory");
+            if (ks + 2 < KS) {
+                const int nb = buf >= 1 ? buf - 1 : 2;   // (ks + 2) % 3
+                glds_2k(a_src + (size_t)(ks + 2) * 8192, voff, lds0 + (unsigned)(nb * DS16_STAGE));
+                glds_2k(b_src + (size_t)(ks + 2) * 8192, voff, lds0 + (unsigned)(nb * DS16_STAGE) + 8192);
+            }
+        } else {
+            glds_wait<0>();
+            __syncthreads();   // stage ks has landed for every wave; everyone is done reading the other buffer
+            if (ks + 1 < KS) {
+                glds_2k(a_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE));
+                glds_2k(b_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE) + 8192);
+            }
         }
         h16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -348,6 +371,7 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+        buf = NSTG == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
     if (tI * DS_BM + DS_BM <= L && tJ * DS_BN + DS_BN <= S) {
@@ -363,11 +387,24 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
 
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
-    const size_t lds = DS16_LDS;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
-    hipLaunchKernelGGL(ds_gemm16_kernel, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
-                       C / 16, NJB, NIB);
+    // Default: three operand stages (prefetch distance 2): 1.78 -> 1.77 ms unmasked, 1.85 -> 1.78 ms with padding masks (round 4).  The
+    // kernel is bound by LDS bandwidth in its main loop (DESIGN.md sections 11, 12), not by the DMA latency, so this is all a deeper
+    // ring buys.  A persistent variant with the epilogue software-pipelined under the next tile's k-stages (two accumulator sets, 2
+    // workgroups per CU, 256 VGPRs with spills) was built and measured at 2.35 ms: the epilogue's slab traffic lands on the same
+    // saturated LDS; it was removed again.
+    const char* ev3 = getenv("CASMTR_DS_GEMM16_STAGES");
+    if (ev3 && ev3[0] == '2') {
+        const size_t lds = DS16_LDS;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
+                           C / 16, NJB, NIB);
+    } else {
+        const size_t lds = DS16_LDS3;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ds_gemm16_kernel<3>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
+                           C / 16, NJB, NIB);
+    }
     CASMTR_CHECK_LAUNCH();
     return 0;
 }

@@ -484,7 +484,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     int rc;
     {
         ProfScope ps(CASMTR_PROF_DS_SPLIT, s);
-        rc = ds_split_launch(feat0, feat1, w, B, L, S, C, temperature, recip, s);
+        rc = ds_split_launch(feat0, feat1, mask0, mask1, w, B, L, S, C, temperature, recip, s);
     }
     if (rc) return rc;
     {
