@@ -425,9 +425,11 @@ int casmtr_qta_coarse_level_tile(const float* q, const float* k, const float* v,
     if (E > 16 || S < 1 || topk < 1 || topk > 60 || topk > S || H < 1 || (long long)S * H * 128 >= (1ll << 31)) return CASMTR_ERR_UNSUPPORTED;
     CoarseTArgs a{};
     a.q = q; a.k = k; a.v = v; a.message = message; a.acc_out = acc_out; a.topk_score = topk_score; a.topk_idx = topk_idx; a.topk_tab = topk_tab;
-    int nw = 4, ns = 4;   // measured at 26x26, B = 8: 4 waves x 4 slots 103 us, 4 x 3 115, 8 x {3,4,6} 111-113, 4 x 6 141 (2 workgroups per CU)
-    { const char* ev = getenv("CASMTR_CT_WAVES"); if (ev && atoi(ev) == 8) nw = 8; }   // measurement knobs
-    { const char* ev = getenv("CASMTR_CT_SLOTS"); if (ev && (atoi(ev) == 3 || atoi(ev) == 6)) ns = atoi(ev); }
+    // measured at 26x26, B = 8 (tools/coarse_tile_sweep.py): 4 waves x 4 slots 103 us, 4 x 3 115, 8 waves x {3,4,6} 105-113 (the 8-wave
+    // barrier costs what the halved DMA volume saves), 4 x 6 141 (2 workgroups per CU).  Instantiated: 4 waves x {3, 4} slots.
+    const int nw = 4;
+    int ns = 4;
+    { const char* ev = getenv("CASMTR_CT_SLOTS"); if (ev && atoi(ev) == 3) ns = 3; }   // measurement knob
     a.temp = temp; a.w_level = w_level; a.topk = topk; a.B = B; a.L = L; a.S = S; a.H = H; a.ntiles = (L + 4 * nw - 1) / (4 * nw); a.BH = B * H;
     a.dbg = g_debug_flags >> 8;   // CASMTR debug flags 256 / 512 / 1024: skip the selection / the A.V arithmetic / the DMA (timing experiments)
     const unsigned grid = (unsigned)((a.BH + 7) / 8 * 8 * a.ntiles);
@@ -442,12 +444,8 @@ int casmtr_qta_coarse_level_tile(const float* q, const float* k, const float* v,
     }
 #define CT_CASE(EE)                                                  \
     if (E <= EE) {                                                   \
-        if (nw == 8 && ns == 3) CT_LAUNCH(EE, 8, 3)                  \
-        else if (nw == 8 && ns == 4) CT_LAUNCH(EE, 8, 4)             \
-        else if (nw == 8 && ns == 6) CT_LAUNCH(EE, 8, 6)             \
-        else if (nw == 4 && ns == 3) CT_LAUNCH(EE, 4, 3)             \
-        else if (nw == 4 && ns == 4) CT_LAUNCH(EE, 4, 4)             \
-        else CT_LAUNCH(EE, 4, 6)                                     \
+        if (ns == 4) CT_LAUNCH(EE, 4, 4)                             \
+        else CT_LAUNCH(EE, 4, 3)                                     \
         CASMTR_CHECK_LAUNCH();                                       \
         return 0;                                                    \
     }
