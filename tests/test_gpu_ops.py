@@ -474,14 +474,14 @@ def test_empty_batch_and_limits(ops):
 
 
 @pytest.mark.parametrize("kernel", ["tile", "three", "fused"])
-@pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid", "wide_range", "indoor", "ragged", "tiny"])
+@pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid", "wide_range", "indoor", "ragged", "tiny", "widest", "one_head"])
 def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
     """coarse-level top-k: the sorted fast path (<= 64 survivors of the lane-maxima threshold; in the tile kernel the exact 32-bit
     packing) and the fallbacks (ties / concentrated rows: iterated argmax; survivors spread over many binades: pair sort) must all
     return the oracle's list, ordered (logit desc, position asc)"""
     monkeypatch.setenv("CASMTR_COARSE_KERNEL", kernel)   # round-4 register-tile kernel (default) | logits / row / A.V kernels | LDS-tile kernel
     r = np.random.default_rng({"random": 1, "all_equal": 2, "one_lane_heavy": 3, "many_ties": 4, "few_valid": 5, "wide_range": 6,
-                               "indoor": 7, "ragged": 8, "tiny": 9}[kind])
+                               "indoor": 7, "ragged": 8, "tiny": 9, "widest": 10, "one_head": 11}[kind])
     B, H, L, S, topk = 1, 2, 40, 676, 32
     if kind == "few_valid":
         S, topk = 48, 8          # fewer keys than lanes
@@ -491,6 +491,10 @@ def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
         L, S, topk = 37, 131, 16      # nothing a multiple of anything
     elif kind == "tiny":
         L, S, topk = 16, 16, 8        # 4 x 4 coarsest grid of the small fixtures
+    elif kind == "widest":
+        H, L, S, topk = 4, 33, 1000, 60   # 16 key blocks (the largest register tile), the largest list the tile kernel takes
+    elif kind == "one_head":
+        H, L, S, topk = 1, 50, 200, 16
     q = r.standard_normal((B, L, H, 32)).astype(np.float32)
     k = r.standard_normal((B, S, H, 32)).astype(np.float32)
     v = r.standard_normal((B, S, H, 32)).astype(np.float32)
