@@ -85,3 +85,13 @@ def test_single_process_passthrough():
     res = cdist.gather_matches(out)
     assert res["n_total"] == 3 and res["mk"].shape == (3, 5)
     assert cdist.shard_range(32, 3, 8) == (12, 16)
+
+
+def test_match_gatherer_needs_pairs_per_step():
+    """holding steps back without pairs_per_step would fold every held step onto the same global pair ids"""
+    import pytest
+    from casmtr_amd import dist as cdist
+    with pytest.raises(ValueError, match="pairs_per_step"):
+        cdist.MatchGatherer(every=4)
+    cdist.MatchGatherer(every=1)                       # the per-batch exchange needs none
+    cdist.MatchGatherer(every=4, pairs_per_step=8)
