@@ -9,8 +9,8 @@
 //          logits of ITS key -- for key block e (64 keys) that is x[e][0..3], i.e. after the pass over all blocks a wave holds 4 whole
 //          rows as x[e][f] with key = 64 e + lane: exactly coarse_row_kernel's register layout, with no transposition and no
 //          workspace.  The d-sum is the sequential d-ascending fmaf chain of the oracle (tools/probes/mfma4x4_layout.hip), so every
-//          index derived from the logits is bit-identical.  Key blocks (64 rows x 128 B) arrive by LDS-DMA through a 3-slot ring
-//          shared by the 4 waves (each issues a quarter of a block, one s_barrier per block, prefetch distance 2).
+//          index derived from the logits is bit-identical.  Key blocks (64 rows x 128 B) arrive by LDS-DMA through a 4-slot ring
+//          shared by the 4 waves (each issues a quarter of a block, one s_barrier per block, prefetch distance 3).
 //   top-k  per row, (logit desc, position asc): theta = a threshold with topk .. topk+4 of the 64 per-lane maxima at or above it
 //          (scalar bisection on ballots: ~6 rounds of 1 VALU + 6 SALU instead of a 21-step wave sort), the <= 64 elements >= theta are
 //          compacted in position order, packed as ((key - theta + 1) << 6) | (63 - slot) -- EXACT, no truncation: the survivors' ordered
