@@ -101,15 +101,15 @@ class CascadeMatching(nn.Module):
         return spread * resp.reshape(B, -1, 1)
 
     @classmethod
-    def finalize(cls, data, level):
+    def finalize(cls, data, level, n=None):
         """Read the match count back (the host sync of `mask.sum() == 0` / torch.where, cascade_matching.py:254-258) and fill
-        the list keys.  No-op unless forward ran with defer_sync=True."""
+        the list keys.  No-op unless forward ran with defer_sync=True.  `n`: the count if the caller has already read it."""
         st = data[f"stage_{level}"]
         pend = st.pop("_pending", None)
         if pend is None:
             return
         sel, hw0, hw1 = pend
-        st.update(**cls._match_dict(sel, int(sel["n"].item()), hw0, hw1, data, level))
+        st.update(**cls._match_dict(sel, int(sel["n"].item()) if n is None else int(n), hw0, hw1, data, level))
         data["m_bids"] = st["m_bids"]
 
     @staticmethod

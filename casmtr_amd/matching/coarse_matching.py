@@ -79,13 +79,14 @@ class CoarseMatching(nn.Module):
             self.finalize(data, level)
 
     @classmethod
-    def finalize(cls, data, level="8c"):
-        """Read the match count back (one host sync, as torch.where at coarse_matching.py:126) and fill the list keys."""
+    def finalize(cls, data, level="8c", n=None):
+        """Read the match count back (one host sync, as torch.where at coarse_matching.py:126) and fill the list keys.
+        `n`: the count if the caller has already read it (HotPath.finalize reads every stage's count in one transfer)."""
         st = data[f"stage_{level}"]
         out = st.pop("_pending", None)
         if out is None:
             return
-        n = int(out["n"].item())
+        n = int(out["n"].item()) if n is None else int(n)
         b_ids, i_ids, j_ids, mconf = (out[k][:n] for k in ("b_ids", "i_ids", "j_ids", "mconf"))
         st.update(**cls._match_dict(b_ids, i_ids, j_ids, mconf, data, level))
 
@@ -98,6 +99,6 @@ class CoarseMatching(nn.Module):
         scale1 = scale * data["scale1"][b_ids] if "scale1" in data else scale
         mkpts0_c = torch.stack([i_ids % w0, torch.div(i_ids, w0, rounding_mode="trunc")], dim=1) * scale0
         mkpts1_c = torch.stack([j_ids % w1, torch.div(j_ids, w1, rounding_mode="trunc")], dim=1) * scale1
-        keep = mconf != 0
+        keep = torch.nonzero(mconf != 0).squeeze(1)   # one host sync for the four filtered lists (boolean indexing syncs per list)
         return {"b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0, "m_bids": b_ids[keep],
                 "mkpts0_c": mkpts0_c[keep], "mkpts1_c": mkpts1_c[keep], "mconf": mconf[keep]}

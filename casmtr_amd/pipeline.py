@@ -294,15 +294,73 @@ class HotPath(torch.nn.Module):
         return self.finalize(out) if finalize else out
 
     def finalize(self, out) -> Dict[str, object]:
-        """one host sync for the whole step: the match counts of every stage"""
+        """The step's read-back: every stage's match count comes to the host in ONE transfer (the reference syncs per stage, at
+        coarse_matching.py:126 and cascade_matching.py:254-258), then the match lists are cut to length.  The 8c stage's filter of
+        padded ground-truth entries (mconf != 0, coarse_matching.py:143-151) is the one further sync."""
         data = out["data"]
-        for st in self.cfg.stages:
-            CascadeMatching.finalize(data, st.level)
-        CoarseMatching.finalize(data, "8c")
+        levels = [st.level for st in self.cfg.stages] + ["8c"]
+        pend = [data[f"stage_{lv}"].get("_pending") for lv in levels]
+        ns = [None] * len(levels)
+        live = [i for i, p in enumerate(pend) if p is not None]
+        if live:
+            counts = torch.cat([(pend[i][0] if isinstance(pend[i], tuple) else pend[i])["n"] for i in live]).tolist()
+            for i, c in zip(live, counts):
+                ns[i] = c
+        for lv, n in zip(levels[:-1], ns[:-1]):
+            CascadeMatching.finalize(data, lv, n=n)
+        CoarseMatching.finalize(data, "8c", n=ns[-1])
         last = data[f"stage_{self.cfg.stages[-1].level}"]
         out.update(m_bids=last["m_bids"], mkpts0=last["mkpts0_c"], mkpts1=last["mkpts1_c"], mconf=last["mconf"],
                    n_coarse=data["stage_8c"]["b_ids"].numel())
         return out
+
+
+class RunAhead:
+    """Keeps the launch stream one step ahead of the read-backs.
+
+    `submit(inp)` enqueues step k+1 on the current stream and then finalises step k on a SIDE stream that waits only for step k's
+    end-of-step event.  On one stream the read-back of step k (its .tolist() / nonzero syncs) would queue behind step k+1's kernels,
+    so the host would come back only when step k+1 had finished and the GPU would idle while step k+2 was being enqueued; with the
+    side stream the host is back after a few tiny kernels and step k+2 is enqueued while step k+1 still runs.  Steps themselves
+    never overlap: all of a step's hot-path kernels stay on the one launch stream, in order.
+
+    The finalised lists are allocated on the side stream; they are marked as used by the launch stream (`record_stream`) so that
+    consumers there (e.g. MatchGatherer's collectives) are safe against the allocator reusing them."""
+
+    def __init__(self, model: "HotPath"):
+        self.model = model
+        self.side = torch.cuda.Stream()
+        self.pend = None
+
+    def submit(self, inp):
+        """-> finalised output of the PREVIOUS submit (None on the first call)"""
+        new = self.model(inp, finalize=False)
+        ev = torch.cuda.Event()
+        ev.record()
+        old, self.pend = self.pend, (new, ev)
+        return self._finish(old)
+
+    def drain(self):
+        """-> finalised output of the last submit (None if there is none)"""
+        old, self.pend = self.pend, None
+        return self._finish(old)
+
+    def _finish(self, old):
+        if old is None:
+            return None
+        out, ev = old
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            res = self.model.finalize(out)
+        # Everything the side stream read (step k's buffers, owned by the launch stream's pool) must be done before those buffers
+        # can be dropped; the tail after finalize's last sync is a handful of gathers.
+        self.side.synchronize()
+        for lv in [st.level for st in self.model.cfg.stages] + ["8c"]:
+            for v in res["data"][f"stage_{lv}"].values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)
+        return res
 
 
 # ----------------------------------------------------------------------------------------------- algorithmic work

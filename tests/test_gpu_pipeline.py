@@ -552,3 +552,30 @@ def test_hip_graph_replay_equals_eager():
     o = gs.finalize(pend)
     assert all(torch.equal(o[k], ref[k]) for k in ref)
     assert int(ref["m_bids"].numel()) > 0
+
+
+def test_run_ahead_side_stream_finalize_equals_eager():
+    """casmtr_amd.pipeline.RunAhead (bench.py's timed loop): step k is finalised on a side stream while step k+1 is already
+    enqueued; with inputs that alternate between two seeds every returned list must equal the eager step's on the same input"""
+    from casmtr_amd.pipeline import HotPath, HotPathConfig, RunAhead, make_synthetic_inputs
+    cfg = HotPathConfig(name="small", image_hw=(256, 320), coarse_layers=2)
+    model = HotPath(cfg).to(DEV)
+    inps = [make_synthetic_inputs(cfg, 2, DEV, seed=s) for s in (7, 8)]
+    with torch.no_grad():
+        model.qta.weight.copy_(inps[0]["weight"])
+    keys = ("m_bids", "mkpts0", "mkpts1", "mconf")
+    refs = []
+    for inp in inps:
+        r = model(inp)
+        refs.append(({k: r[k].clone() for k in keys},
+                     {k: r["data"]["stage_8c"][k].clone() for k in ("b_ids", "i_ids", "j_ids", "mconf", "m_bids", "mkpts0_c")}))
+    assert not torch.equal(refs[0][0]["mconf"], refs[1][0]["mconf"])
+    ra = RunAhead(model)
+    outs = [ra.submit(inps[i & 1]) for i in range(24)] + [ra.drain()]
+    assert outs[0] is None and ra.drain() is None
+    for i, o in enumerate(outs[1:]):
+        ref, ref8 = refs[i & 1]
+        for k in keys:
+            assert torch.equal(o[k], ref[k]), (i, k)
+        for k in ref8:
+            assert torch.equal(o["data"]["stage_8c"][k], ref8[k]), (i, k)
