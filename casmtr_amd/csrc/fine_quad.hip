@@ -96,11 +96,165 @@ __device__ __forceinline__ void merge_round(unsigned (&s)[8], bool odd) {
     bitonic8_desc(s);
 }
 
+// Softmax over an item's candidates (+ the top-k selection of levels that feed a finer one), one series (child) per 16-lane row.
+// In: lg[p][f] = logit of candidate 64 p + lane for child f.  Out: P[child][parity][m] in Pld (operand A of the V chunks); EXACT: lane
+// (f, j) gets rank (j&1)*8 + j/2 of child f: its probability (out_sc) and absolute key index (out_idx).  t2 = the item's staged parent list.
+template <int NPASS, bool EXACT, bool FULL>
+__device__ __forceinline__ void softmax_select(const FineQArgs& a, const f32x4 (&lg)[NPASS], float* Pld, const int* t2, int lane, int K,
+                                               int w1p, float& out_sc, int& out_idx) {
+    constexpr int KMAX = 64 * NPASS;
+    constexpr int E = KMAX / 16;
+    constexpr int KS = KMAX + 4;
+    constexpr int PST = 32 * NPASS + 4;
+    const int f = lane >> 4, j = lane & 15;
+    float* Sld = Pld;   // [4][KS]
+#pragma unroll
+    for (int pp = 0; pp < NPASS; ++pp)
+#pragma unroll
+        for (int ff = 0; ff < 4; ++ff) Sld[ff * KS + 64 * pp + lane] = lg[pp][ff];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float lv[E];
+    unsigned xk[E];
+    const f32x4* sp = reinterpret_cast<const f32x4*>(Sld + f * KS + j * E);
+#pragma unroll
+    for (int e4 = 0; e4 < E / 4; ++e4) {
+        const f32x4 v = sp[e4];
+        lv[4 * e4 + 0] = v.x; lv[4 * e4 + 1] = v.y; lv[4 * e4 + 2] = v.z; lv[4 * e4 + 3] = v.w;
+    }
+    float m;
+    if constexpr (EXACT) {
+        unsigned lm = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            xk[e] = (FULL || j * E + e < K) ? f2ord(lv[e]) : 0u;
+            lm = max(lm, xk[e]);
+        }
+        m = ord2f(row16_max_u32(lm));
+    } else {   // no selection: the maximum only centres the exponentials
+        float fm = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) fm = (FULL || j * E + e < K) ? fmaxf(fm, lv[e]) : fm;
+        fm = fmaxf(fm, dpp_f32<0xB1>(fm));
+        fm = fmaxf(fm, dpp_f32<0x4E>(fm));
+        fm = fmaxf(fm, dpp_f32<0x141>(fm));
+        m = fmaxf(fm, dpp_f32<0x140>(fm));
+    }
+    float ps[E];
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        ps[e] = (FULL || j * E + e < K) ? __expf(lv[e] - m) : 0.f;
+        sum += ps[e];
+    }
+    sum = __builtin_amdgcn_rcpf(row16_sum_f32(sum));   // 1 ulp: the probabilities carry a 1e-4 tolerance, no index depends on them
+#pragma unroll
+    for (int e = 0; e < E; ++e) ps[e] = ps[e] * sum;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // every lane has its logits: the buffer becomes P
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // candidate j*E + e -> P[f][e & 1][(j*E + e) >> 1]
+    if constexpr (E == 4) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(Pld + (f * 2 + 0) * PST + 2 * j) = (f32x2){ps[0], ps[2]};
+        *reinterpret_cast<f32x2*>(Pld + (f * 2 + 1) * PST + 2 * j) = (f32x2){ps[1], ps[3]};
+    } else {
+        *reinterpret_cast<f32x4*>(Pld + (f * 2 + 0) * PST + 4 * j) = (f32x4){ps[0], ps[2], ps[4], ps[6]};
+        *reinterpret_cast<f32x4*>(Pld + (f * 2 + 1) * PST + 4 * j) = (f32x4){ps[1], ps[3], ps[5], ps[7]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (EXACT) {
+        // ---- selection on the logits, (logit desc, position asc); lane j ends up with rank (j&1)*8 + j/2
+        const bool odd = j & 1;
+        const int rank = (j & 1) * 8 + (j >> 1), topm1 = a.topk - 1;
+        unsigned s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            s[e] = (e < E && xk[e < E ? e : 0] != 0u) ? ((xk[e < E ? e : 0] & ~127u) | (unsigned)(127 - (j * E + e))) : 0u;
+        sort8_desc(s);
+        unsigned loc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) loc[e] = s[e];
+        {   // round 1: the pair's 16 elements, sorted across (even, odd)
+            unsigned x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned tt = dpp_u32<0xB1>(s[7 - i]);
+                x[i] = odd ? min(s[i], tt) : max(s[i], tt);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = x[i];
+            bitonic8_desc(s);
+        }
+        merge_round<0x1B>(s, odd);    // quad_perm [3,2,1,0]
+        merge_round<0x141>(s, odd);   // row_half_mirror
+        merge_round<0x140>(s, odd);   // row_mirror
+        unsigned mine = s[0];
+        {
+            const int sel = j >> 1;
+            const unsigned m01 = (sel & 1) ? s[1] : s[0], m23 = (sel & 1) ? s[3] : s[2];
+            const unsigned m45 = (sel & 1) ? s[5] : s[4], m67 = (sel & 1) ? s[7] : s[6];
+            const unsigned m03 = (sel & 2) ? m23 : m01, m47 = (sel & 2) ? m67 : m45;
+            mine = (sel & 4) ? m47 : m03;
+        }
+        // is the packed order the exact order for the first topk ranks?  (see the file header)
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) bad |= ((s[i] ^ s[i + 1]) < 128u) && ((odd ? 8 : 0) + i < topm1);
+        {
+            const unsigned tt = dpp_u32<0xB1>(s[0]);
+            bad |= !odd && ((s[7] ^ tt) < 128u) && (7 < topm1);
+        }
+        const int jstar = (topm1 & 7) * 2 + (topm1 >> 3);
+        const unsigned thr = row16_max_u32(j == jstar ? mine : 0u) & ~127u;
+        unsigned cntge = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cntge += (loc[e] >= thr) ? 1u : 0u;
+        bad |= row16_sum_u32(cntge) != (unsigned)a.topk;
+        int my_pos = 127 - (int)(mine & 127u);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+            // exact path: iterated row argmax on the full 32-bit keys, first position by ballot / ffs
+            unsigned key[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) key[e] = xk[e];
+            for (int tk = 0; tk < a.topk; ++tk) {
+                unsigned cur = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) cur = max(cur, key[e]);
+                const unsigned rm = row16_max_u32(cur);
+                const unsigned long long bal = __ballot(cur == rm);
+                const unsigned bits = (unsigned)(bal >> (f * 16)) & 0xFFFFu;
+                const int wj = __ffs(bits) - 1;   // first lane of the row holding the maximum -> smallest position
+                unsigned kp1 = 0;
+                if (j == wj) {
+                    bool done = false;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool hit = !done && key[e] == rm;
+                        if (hit) { kp1 = (unsigned)(j * E + e + 1); key[e] = 0u; done = true; }
+                    }
+                }
+                const unsigned wp1 = row16_max_u32(kp1);
+                if (rank == tk) my_pos = (int)wp1 - 1;
+            }
+        }
+        if (rank >= a.topk) my_pos = 0;
+        const int c = my_pos;
+        out_sc = Pld[(f * 2 + (c & 1)) * PST + (c >> 1)];
+        const int par = t2[((c >> 2) & 1) * 16 + (c >> 3)];
+        const int qy1 = a.div_magic ? (int)__umulhi((unsigned)par, a.div_magic) : par;
+        const int qx1 = par - qy1 * w1p;
+        out_idx = (2 * qy1 + ((c >> 1) & 1)) * a.w1 + 2 * qx1 + (c & 1);   // absolute index on the h1 x w1 grid (:224)
+    }
+}
+
 template <int NPASS, bool EXACT, bool FULL>   // EXACT: the level feeds a finer one (top-k requested): bit-exact sequential d-chain;
                                               // FULL: the lists have exactly 64 * NPASS candidates (every shipped config): no per-element bound test
 __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(const FineQArgs a) {
     constexpr int KMAX = 64 * NPASS;
-    constexpr int E = KMAX / 16;          // elements per lane in the series-per-row phase
     constexpr int KS = KMAX + 4;          // row stride of the logits transposition buffer
     constexpr int PST = 32 * NPASS + 4;   // stride of one (child, parity) run of probabilities
     constexpr int P_FLOATS = 8 * PST;
@@ -306,151 +460,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             asm volatile("" : "+v"(lg[p]));   // keep the pass's arithmetic inside the pass
         });
         // ================================================================== softmax (+ top-k), one series (child) per 16-lane row
-        const int f = lane >> 4, j = lane & 15;
-        {
-            float* Sld = Pld;   // [4][KS]
-#pragma unroll
-            for (int pp = 0; pp < NPASS; ++pp)
-#pragma unroll
-                for (int ff = 0; ff < 4; ++ff) Sld[ff * KS + 64 * pp + lane] = lg[pp][ff];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float lv[E];
-            unsigned xk[E];
-            const f32x4* sp = reinterpret_cast<const f32x4*>(Sld + f * KS + j * E);
-#pragma unroll
-            for (int e4 = 0; e4 < E / 4; ++e4) {
-                const f32x4 v = sp[e4];
-                lv[4 * e4 + 0] = v.x; lv[4 * e4 + 1] = v.y; lv[4 * e4 + 2] = v.z; lv[4 * e4 + 3] = v.w;
-            }
-            float m;
-            if constexpr (EXACT) {
-                unsigned lm = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    xk[e] = (FULL || j * E + e < K) ? f2ord(lv[e]) : 0u;
-                    lm = max(lm, xk[e]);
-                }
-                m = ord2f(row16_max_u32(lm));
-            } else {   // no selection: the maximum only centres the exponentials
-                float fm = -3.0e38f;
-#pragma unroll
-                for (int e = 0; e < E; ++e) fm = (FULL || j * E + e < K) ? fmaxf(fm, lv[e]) : fm;
-                fm = fmaxf(fm, dpp_f32<0xB1>(fm));
-                fm = fmaxf(fm, dpp_f32<0x4E>(fm));
-                fm = fmaxf(fm, dpp_f32<0x141>(fm));
-                m = fmaxf(fm, dpp_f32<0x140>(fm));
-            }
-            float ps[E];
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                ps[e] = (FULL || j * E + e < K) ? __expf(lv[e] - m) : 0.f;
-                sum += ps[e];
-            }
-            sum = __builtin_amdgcn_rcpf(row16_sum_f32(sum));   // 1 ulp: the probabilities carry a 1e-4 tolerance, no index depends on them
-#pragma unroll
-            for (int e = 0; e < E; ++e) ps[e] = ps[e] * sum;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // every lane has its logits: the buffer becomes P
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // candidate j*E + e -> P[f][e & 1][(j*E + e) >> 1]
-            if constexpr (E == 4) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<f32x2*>(Pld + (f * 2 + 0) * PST + 2 * j) = (f32x2){ps[0], ps[2]};
-                *reinterpret_cast<f32x2*>(Pld + (f * 2 + 1) * PST + 2 * j) = (f32x2){ps[1], ps[3]};
-            } else {
-                *reinterpret_cast<f32x4*>(Pld + (f * 2 + 0) * PST + 4 * j) = (f32x4){ps[0], ps[2], ps[4], ps[6]};
-                *reinterpret_cast<f32x4*>(Pld + (f * 2 + 1) * PST + 4 * j) = (f32x4){ps[1], ps[3], ps[5], ps[7]};
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if constexpr (EXACT) {
-                // ---- selection on the logits, (logit desc, position asc); lane j ends up with rank (j&1)*8 + j/2
-                const bool odd = j & 1;
-                const int rank = (j & 1) * 8 + (j >> 1), topm1 = a.topk - 1;
-                unsigned s[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    s[e] = (e < E && xk[e < E ? e : 0] != 0u) ? ((xk[e < E ? e : 0] & ~127u) | (unsigned)(127 - (j * E + e))) : 0u;
-                sort8_desc(s);
-                unsigned loc[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) loc[e] = s[e];
-                {   // round 1: the pair's 16 elements, sorted across (even, odd)
-                    unsigned x[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const unsigned tt = dpp_u32<0xB1>(s[7 - i]);
-                        x[i] = odd ? min(s[i], tt) : max(s[i], tt);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s[i] = x[i];
-                    bitonic8_desc(s);
-                }
-                merge_round<0x1B>(s, odd);    // quad_perm [3,2,1,0]
-                merge_round<0x141>(s, odd);   // row_half_mirror
-                merge_round<0x140>(s, odd);   // row_mirror
-                unsigned mine = s[0];
-                {
-                    const int sel = j >> 1;
-                    const unsigned m01 = (sel & 1) ? s[1] : s[0], m23 = (sel & 1) ? s[3] : s[2];
-                    const unsigned m45 = (sel & 1) ? s[5] : s[4], m67 = (sel & 1) ? s[7] : s[6];
-                    const unsigned m03 = (sel & 2) ? m23 : m01, m47 = (sel & 2) ? m67 : m45;
-                    mine = (sel & 4) ? m47 : m03;
-                }
-                // is the packed order the exact order for the first topk ranks?  (see the file header)
-                bool bad = false;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) bad |= ((s[i] ^ s[i + 1]) < 128u) && ((odd ? 8 : 0) + i < topm1);
-                {
-                    const unsigned tt = dpp_u32<0xB1>(s[0]);
-                    bad |= !odd && ((s[7] ^ tt) < 128u) && (7 < topm1);
-                }
-                const int jstar = (topm1 & 7) * 2 + (topm1 >> 3);
-                const unsigned thr = row16_max_u32(j == jstar ? mine : 0u) & ~127u;
-                unsigned cntge = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) cntge += (loc[e] >= thr) ? 1u : 0u;
-                bad |= row16_sum_u32(cntge) != (unsigned)a.topk;
-                int my_pos = 127 - (int)(mine & 127u);
-                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
-                    // exact path: iterated row argmax on the full 32-bit keys, first position by ballot / ffs
-                    unsigned key[E];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) key[e] = xk[e];
-                    for (int tk = 0; tk < a.topk; ++tk) {
-                        unsigned cur = 0;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) cur = max(cur, key[e]);
-                        const unsigned rm = row16_max_u32(cur);
-                        const unsigned long long bal = __ballot(cur == rm);
-                        const unsigned bits = (unsigned)(bal >> (f * 16)) & 0xFFFFu;
-                        const int wj = __ffs(bits) - 1;   // first lane of the row holding the maximum -> smallest position
-                        unsigned kp1 = 0;
-                        if (j == wj) {
-                            bool done = false;
-#pragma unroll
-                            for (int e = 0; e < E; ++e) {
-                                const bool hit = !done && key[e] == rm;
-                                if (hit) { kp1 = (unsigned)(j * E + e + 1); key[e] = 0u; done = true; }
-                            }
-                        }
-                        const unsigned wp1 = row16_max_u32(kp1);
-                        if (rank == tk) my_pos = (int)wp1 - 1;
-                    }
-                }
-                if (rank >= a.topk) my_pos = 0;
-                const int c = my_pos;
-                pend_sc = Pld[(f * 2 + (c & 1)) * PST + (c >> 1)];
-                const int par = t2[((c >> 2) & 1) * 16 + (c >> 3)];
-                const int qy1 = a.div_magic ? (int)__umulhi((unsigned)par, a.div_magic) : par;
-                const int qx1 = par - qy1 * w1p;
-                pend_idx = (2 * qy1 + ((c >> 1) & 1)) * a.w1 + 2 * qx1 + (c & 1);   // absolute index on the h1 x w1 grid (:224)
-            }
-        }
+        softmax_select<NPASS, EXACT, FULL>(a, lg, Pld, t2, lane, K, w1p, pend_sc, pend_idx);
         // ================================================================== V chunks; then the next item's K pass 0
         f32x4 acc[4];
 #pragma unroll

@@ -219,11 +219,14 @@ class QTAttB(nn.Module):
         self._last_levels = per_level if want_topk else None
         return acc
 
-    def forward_multi(self, calls):
+    def forward_multi(self, calls, split_fine=False):
         """calls: list of (queries, keys, values) pyramid triples of identical shapes whose results do not depend on each other -- the two
         directions of a transformer layer (transformer.py:295-300: `layer(feat0, feat1), layer(feat1, feat0)` are computed from the same
         inputs; the 'self' layers likewise).  One layout launch writes all of them into doubled-batch operands and every level kernel
-        runs once -> list of messages, equal to [self.forward(*c) for c in calls]."""
+        runs once -> list of messages, equal to [self.forward(*c) for c in calls].
+        split_fine: only the layout pass and the coarsest level (a dense tile kernel whose short grid gains from the doubled batch)
+        share their launches; the finer levels (persistent gather kernels walking an XCD's L2 slice pair by pair) run once per call on
+        their half of the operands."""
         n = len(calls[0][0])
         hw_q = [tuple(q.shape[2:]) for q in reversed(calls[0][0])]
         hw_k = [tuple(k.shape[2:]) for k in reversed(calls[0][1])]
@@ -235,14 +238,28 @@ class QTAttB(nn.Module):
         B = flat[0][0].shape[0]
         groups = [[f[j].float() for f in flat] for j in range(3 * n)]
         laid = ops.nchw_to_quads_grouped(groups, [j < 3 for j in range(3 * n)])
+        if split_fine:
+            return self._run_levels_quad(laid[:3], laid[3:], hw_q, hw_k, False, groups=len(calls))
         acc = self._run_levels_quad(laid[:3], laid[3:], hw_q, hw_k, False)
         return [acc[g * B:(g + 1) * B] for g in range(len(calls))]
 
-    def _run_levels_quad(self, coarse, quads, hw_q, hw_k, want_topk):
+    def _run_levels_quad(self, coarse, quads, hw_q, hw_k, want_topk, groups=1):
         n = len(hw_q)
         weight = self._level_weights()
         out = ops.qta_coarse_level(*coarse, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=want_topk)
         acc, tab = out["acc"], out["topk_tab"]
+        if groups > 1:   # forward_multi(split_fine=True): the operands hold `groups` calls back to back; finer levels per call -> list
+            B = acc.shape[0] // groups
+            sls = [slice(g * B, (g + 1) * B) for g in range(groups)]
+            state = [(acc[sl], tab[sl]) for sl in sls]
+            for g, i in [(g, i) for g in range(groups) for i in range(1, n)]:   # call-major (level-major measured the same)
+                q, k, v = (x[sls[g]] for x in quads[3 * (i - 1):3 * i])
+                a, t = state[g]
+                o = ops.qta_fine_level_quad(q, k, v, t, hw_q[i], hw_k[i], self.nhead, self.topks[i] if i < n - 1 else 0,
+                                            w_level=weight[i], acc_in=a, want_message=False, want_topk=False)
+                state[g] = (o["acc"], o["topk_tab"])
+            self._last_levels = None
+            return [a for a, _ in state]
         per_level = [out]
         for i in range(1, n):
             q, k, v = quads[3 * (i - 1):3 * i]

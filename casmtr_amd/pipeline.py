@@ -61,10 +61,12 @@ class HotPathConfig:
                                       # ([B,N,C] tokens in; q/k/v + output projections and the pyramid inside the step)
     masked: bool = False              # MegaDepth-style padding masks (BASELINE configs[2]): bottom / right up to 20 % padded
     fresh_inputs: bool = True         # every attention layer reads its own q/k/v tensors (False: one shared set, as round 1)
-    paired_layers: bool = False       # the two directions of a layer (independent in the reference, transformer.py:295-300 / :549) share
-                                      # their launches: one layout pass, every level kernel once on the doubled batch.  Off: measured
-                                      # 571.5 against 575.4 pairs/s (coarsest level faster, the gather kernels slower on 16 pairs); the two
-                                      # directions on two HIP streams instead: 565 against 588
+    paired_layers: object = "coarse"  # False | True | "coarse".  The two directions of a layer are independent in the reference
+                                      # (transformer.py:295-300 / :549).  "coarse" (default): QTAttB's layout pass and coarsest level run
+                                      # once for both directions on the doubled batch, the finer levels once per direction (bit-equal to
+                                      # separate calls; 12.02-12.03 against 12.15-12.27 ms per step, round 4).  True: every kernel once on
+                                      # the doubled batch (12.18-12.19: the gather kernels lose on 16 pairs what the coarsest level gains).
+                                      # The two directions on two HIP streams instead: 565 against 588 pairs/s (round 3)
     ds_gemm: str = "split"            # CoarseMatching(gemm=...): 'split' = f16 matrix pipe + exact argmax re-decision (ops.ds_gemm_mode),
                                       # 'exact' = every logit from the fp32 chain; CASMTR_DS_GEMM overrides (bench.py's exact leg)
     implicit_windows: bool = True     # cascade window lists travel as topk_pos [B,N/4,25,2]; the int64 [B,N,100]
@@ -244,7 +246,8 @@ class HotPath(torch.nn.Module):
             pairs = ((0, 0), (1, 1)) if layer % 2 == 0 else ((0, 1), (1, 0))   # 'self' / 'cross'
             if not cfg.callers and cfg.paired_layers:
                 # the two directions of a layer are independent in the reference (transformer.py:295-300): shared launches
-                msgs += self.qta.forward_multi([(inp[f"cq{a}"][li], inp[f"ck{b}"][li], inp[f"cv{b}"][li]) for a, b in pairs])
+                msgs += self.qta.forward_multi([(inp[f"cq{a}"][li], inp[f"ck{b}"][li], inp[f"cv{b}"][li]) for a, b in pairs],
+                                               split_fine=cfg.paired_layers == "coarse")
                 continue
             for a, b in pairs:
                 if cfg.callers:
@@ -272,7 +275,7 @@ class HotPath(torch.nn.Module):
                     blk = self.cascade_blocks[si][layer]
                     m0, i01 = blk(inp[f"{lvl}x0"], inp[f"{lvl}x1"], h, w, idx=tp01, rel_pos=rel01, want_idx=want_idx)
                     m1, i10 = blk(inp[f"{lvl}x1"], inp[f"{lvl}x0"], h, w, idx=tp10, rel_pos=rel10, want_idx=want_idx)
-                elif cfg.paired_layers and not want_idx and rel01 is None and rel10 is None:
+                elif cfg.paired_layers is True and not want_idx and rel01 is None and rel10 is None:
                     m0, m1 = self.cascade_qta[si].forward_multi([(inp[f"{lvl}q0"][li], inp[f"{lvl}k1"][li], inp[f"{lvl}v1"][li], tp01),
                                                                  (inp[f"{lvl}q1"][li], inp[f"{lvl}k0"][li], inp[f"{lvl}v0"][li], tp10)])
                     i01 = i10 = None

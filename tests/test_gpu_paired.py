@@ -27,8 +27,9 @@ def test_qtattb_forward_multi_equals_separate_calls():
         calls = [(_pyr(g, 2, 256, 40, 32), _pyr(g, 2, 256, 40, 32), _pyr(g, 2, 256, 40, 32)) for _ in range(2)]
         sep = [att(*c) for c in calls]
         both = att.forward_multi(calls)
-    for a, b in zip(sep, both):
-        assert torch.equal(a, b)
+        hybrid = att.forward_multi(calls, split_fine=True)   # shared layout + coarsest level, finer levels per call
+    for a, b, c in zip(sep, both, hybrid):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_cascade_forward_multi_equals_separate_calls():

@@ -15,7 +15,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = {"fine_quad.hip": ("fine_quad_kernel", 8), "cascade_quad.hip": ("cascade_quad_kernel", 2), "coarse_tile.hip": ("coarse_tile_kernel", 10)}
+FILES = {"fine_quad.hip": (("fine_quad_kernel", 8),), "cascade_quad.hip": (("cascade_quad_kernel", 2),),
+         "coarse_tile.hip": (("coarse_tile_kernel", 10),)}
 NO_COMPILER_VMEM = {"fine_quad_kernel"}          # no vector load / vmcnt wait outside the inline-asm blocks
 SPILL_EXEMPT = re.compile(r"coarse_tile_kernelILi16E")   # S > 704 keys: 144 VGPRs at 3 waves per SIMD, spill-free today but not promised
 
@@ -62,12 +63,13 @@ def check(asm_text, kernel, n_expected):
 def main():
     bad = []
     with tempfile.TemporaryDirectory() as td:
-        for f, (kernel, n) in FILES.items():
+        for f, kernels in FILES.items():
             src = os.path.join(ROOT, "casmtr_amd", "csrc", f)
             out = os.path.join(td, f + ".s")
             subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
                                    "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
-            bad += check(open(out).read(), kernel, n)
+            for kernel, n in kernels:
+                bad += check(open(out).read(), kernel, n)
     for b in bad:
         print("FAIL:", b)
     print("ok" if not bad else f"{len(bad)} problem(s)")
