@@ -13,11 +13,16 @@ static std::vector<Pair> g_ev[CASMTR_PROF_COUNT];
 static std::vector<Pair> g_free;
 static Pair g_open[CASMTR_PROF_COUNT];
 
+// Timing-only events: no system-scope fence (L2 write-back + invalidate) when they are recorded; nothing reads device memory through
+// them.  Measured: the timed kernel 1 % shorter (195.8 against 197.6 us), the step 0.02 ms; the 5.8 us of idle stream that a rocprofv3
+// kernel trace shows behind every record (24 records per step = 0.14 ms of 12.1) is the barrier packet itself and stays.
+static unsigned event_flags() { return (unsigned)hipEventDisableSystemFence; }
+
 void prof_begin(int id, hipStream_t s) {   // id < 0: never timed
     if (id < 0 || !(g_mask >> id & 1u)) return;
     Pair p;
     if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
-    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    else { (void)hipEventCreateWithFlags(&p.a, event_flags()); (void)hipEventCreateWithFlags(&p.b, event_flags()); }
     (void)hipEventRecord(p.a, s);
     g_open[id] = p;
 }
@@ -64,8 +69,8 @@ extern "C" int casmtr_prof_enable_only(int id) {
 extern "C" int casmtr_prof_reserve(int pairs) {
     for (int i = (int)g_free.size(); i < pairs; ++i) {
         Pair p;
-        hipError_t e = hipEventCreate(&p.a);
-        if (e == hipSuccess) e = hipEventCreate(&p.b);
+        hipError_t e = hipEventCreateWithFlags(&p.a, event_flags());
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p.b, event_flags());
         if (e != hipSuccess) return (int)e;
         g_free.push_back(p);
     }
