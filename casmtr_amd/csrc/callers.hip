@@ -110,8 +110,7 @@ extern "C" int casmtr_linear_fwd(const float* const* x, const float* const* w, c
         lb.x[i] = x[i]; lb.w[i] = w[i]; lb.bias[i] = bias ? bias[i] : nullptr; lb.y[i] = y[i];
     }
     const int NIB = (M + LIN_BM - 1) / LIN_BM, NJB = (N + LIN_BN - 1) / LIN_BN;
-    ProfScope ps(CASMTR_PROF_LINEAR, (hipStream_t)stream);
-    hipLaunchKernelGGL(linear_nt_kernel, dim3(NIB * NJB, nprob), dim3(256), 0, (hipStream_t)stream, lb, M, N, K, NJB);
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_LINEAR, linear_nt_kernel, dim3(NIB * NJB, nprob), dim3(256), 0, (hipStream_t)stream, lb, M, N, K, NJB);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }

@@ -433,14 +433,13 @@ int casmtr_qta_coarse_level_tile(const float* q, const float* k, const float* v,
     a.temp = temp; a.w_level = w_level; a.topk = topk; a.B = B; a.L = L; a.S = S; a.H = H; a.ntiles = (L + 4 * nw - 1) / (4 * nw); a.BH = B * H;
     a.dbg = g_debug_flags >> 8;   // CASMTR debug flags 256 / 512 / 1024: skip the selection / the A.V arithmetic / the DMA (timing experiments)
     const unsigned grid = (unsigned)((a.BH + 7) / 8 * 8 * a.ntiles);
-    ProfScope ps(CASMTR_PROF_COARSE_FUSED, s);
 #define CT_LAUNCH(EE, NWW, NSS)                                                                                                      \
     {                                                                                                                                \
         const size_t lds = sizeof(float) * (NSS * 2048 + NWW * 512);                                                                 \
         if (lds > 48 * 1024)                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_tile_kernel<EE, NWW, NSS>),                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
-        hipLaunchKernelGGL((coarse_tile_kernel<EE, NWW, NSS>), dim3(grid), dim3(64 * NWW), lds, s, a);                               \
+        CASMTR_LAUNCH_TIMED(CASMTR_PROF_COARSE_FUSED, (coarse_tile_kernel<EE, NWW, NSS>), dim3(grid), dim3(64 * NWW), lds, s, a);    \
     }
 #define CT_CASE(EE)                                                  \
     if (E <= EE) {                                                   \

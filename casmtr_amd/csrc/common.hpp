@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <type_traits>
 
@@ -193,6 +194,18 @@ extern int g_debug_flags;   // casmtr_debug_set(): phase-elimination switches fo
 #define CASMTR_DBG_NO_MATH 2     // DMA kernels: skip the per-stage LDS reads and arithmetic
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
+// Single-kernel scope with the two events ATTACHED TO THE DISPATCH (hipExtLaunchKernelGGL): they carry the kernel's own start / end
+// timestamps and put no barrier packet on the stream.  (Events recorded around a launch cost 5.8 us of idle stream each: rocprofv3
+// kernel trace of the bench step, 24 records per step.)  prof_pair() -> false when kernel `id` is not being timed.
+bool prof_pair(int id, hipEvent_t* a, hipEvent_t* b);
+#define CASMTR_LAUNCH_TIMED(id, kernel, grid, block, lds, stream, ...)                                          \
+    do {                                                                                                       \
+        hipEvent_t ea__, eb__;                                                                                 \
+        if (casmtr::prof_pair(id, &ea__, &eb__))                                                               \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ea__, eb__, 0, __VA_ARGS__);               \
+        else                                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+    } while (0)
 struct ProfScope {
     int id; hipStream_t s;
     ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }

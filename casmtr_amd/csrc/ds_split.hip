@@ -397,13 +397,13 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
     if (ev3 && ev3[0] == '2') {
         const size_t lds = DS16_LDS;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
-                           C / 16, NJB, NIB);
+        CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1,
+                            sim, w, L, S, C / 16, NJB, NIB);
     } else {
         const size_t lds = DS16_LDS3;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ds_gemm16_kernel<3>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1, sim, w, L, S,
-                           C / 16, NJB, NIB);
+        CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<3>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1,
+                            sim, w, L, S, C / 16, NJB, NIB);
     }
     CASMTR_CHECK_LAUNCH();
     return 0;

@@ -488,8 +488,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     }
     if (rc) return rc;
     {
-        ProfScope ps(CASMTR_PROF_DS_GEMM, s);
-        rc = ds_gemm16_launch(mask0, mask1, sim_ws, w, B, L, S, C, s);
+        rc = ds_gemm16_launch(mask0, mask1, sim_ws, w, B, L, S, C, s);   // timed inside (events attached to the dispatch)
     }
     if (rc) return rc;
     {

@@ -1,5 +1,6 @@
-// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's live roofline numbers).
-// Disabled by default: prof_begin/prof_end are a branch on a global flag.
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers).  Single-kernel scopes
+// (CASMTR_LAUNCH_TIMED, common.hpp) attach the event pair to the dispatch itself; scopes that span several launches (ProfScope) record
+// events around them.  Disabled by default: both are a branch on a global mask.
 #include <stdlib.h>
 #include <vector>
 #include "common.hpp"
@@ -25,6 +26,15 @@ void prof_begin(int id, hipStream_t s) {   // id < 0: never timed
     else { (void)hipEventCreateWithFlags(&p.a, event_flags()); (void)hipEventCreateWithFlags(&p.b, event_flags()); }
     (void)hipEventRecord(p.a, s);
     g_open[id] = p;
+}
+bool prof_pair(int id, hipEvent_t* a, hipEvent_t* b) {
+    if (id < 0 || !(g_mask >> id & 1u)) return false;
+    Pair p;
+    if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+    else { (void)hipEventCreateWithFlags(&p.a, event_flags()); (void)hipEventCreateWithFlags(&p.b, event_flags()); }
+    g_ev[id].push_back(p);
+    *a = p.a; *b = p.b;
+    return true;
 }
 void prof_end(int id, hipStream_t s) {
     if (id < 0 || !(g_mask >> id & 1u)) return;

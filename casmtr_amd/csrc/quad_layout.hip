@@ -130,8 +130,7 @@ extern "C" int casmtr_nchw_to_quads_multi(const float* const* src, float* const*
         tiles += tok ? ((h[i] * w[i] + 63) / 64) * ((C[i] + 63) / 64) : (C[i] / 32) * (h[i] / 2) * ((w[i] / 2 + 31) / 32);
     }
     lb.tile_begin[n] = tiles;
-    ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream);
-    hipLaunchKernelGGL(nchw_to_quads_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, lb);
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_LAYOUT, nchw_to_quads_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, lb);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }

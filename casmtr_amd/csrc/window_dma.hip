@@ -297,9 +297,8 @@ static int launch_wm_pos(const float* fq, const float* fk, const int64_t* tp, co
     const long long work = (long long)B * nquads;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
-    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
-    hipLaunchKernelGGL((window_match_pos_kernel<C, RECIP, NP1>), dim3((unsigned)blocks), dim3(128), lds, s, fq, fk, tp, mq, mk, sqrtC,
-                       1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, B, h0, w0, h1, w1, KW, dil, nquads, g_debug_flags);
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_WINDOW_MATCH, (window_match_pos_kernel<C, RECIP, NP1>), dim3((unsigned)blocks), dim3(128), lds, s, fq, fk,
+                        tp, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, B, h0, w0, h1, w1, KW, dil, nquads, g_debug_flags);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
