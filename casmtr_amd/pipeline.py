@@ -327,8 +327,13 @@ class RunAhead:
     side stream the host is back after a few tiny kernels and step k+2 is enqueued while step k+1 still runs.  Steps themselves
     never overlap: all of a step's hot-path kernels stay on the one launch stream, in order.
 
-    The finalised lists are allocated on the side stream; they are marked as used by the launch stream (`record_stream`) so that
-    consumers there (e.g. MatchGatherer's collectives) are safe against the allocator reusing them."""
+    The finalised lists are allocated from the side stream's pool and consumed on the launch stream (e.g. MatchGatherer's
+    collectives).  They are NOT `record_stream`-ed: the allocator would record one event on the launch stream per tensor when it is
+    freed (7 per step, 5.6 us of idle stream each: the 40 us hole at every step boundary in a rocprofv3 trace, tools/trace_gaps.py).
+    It is not needed either: a freed block is only ever reused by a LATER finalize on this private side stream, and every finalize
+    starts by waiting for an event recorded on the launch stream after everything the (single) host thread had enqueued there before
+    -- including every consumer of the block.  The host waits for the side stream before it returns, so nothing is freed while the
+    side stream still works on it."""
 
     def __init__(self, model: "HotPath"):
         self.model = model
@@ -352,17 +357,12 @@ class RunAhead:
         if old is None:
             return None
         out, ev = old
-        main = torch.cuda.current_stream()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             res = self.model.finalize(out)
         # Everything the side stream read (step k's buffers, owned by the launch stream's pool) must be done before those buffers
         # can be dropped; the tail after finalize's last sync is a handful of gathers.
         self.side.synchronize()
-        for lv in [st.level for st in self.model.cfg.stages] + ["8c"]:
-            for v in res["data"][f"stage_{lv}"].values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(main)
         return res
 
 
