@@ -472,10 +472,10 @@ class CascadeQTAttB(nn.Module):
         q, k, v = ops.nchw_to_tokens_multi([t.float() for t in (query, key, value)])
         return self.forward_tokens(q, k, v, hw_q, hw_k, topk_pos, rel_pos, want_idx)
 
-    def forward_multi(self, calls):
+    def forward_multi(self, calls, split_attn=False):
         """calls: list of (query, key, value, topk_pos) of identical shapes, independent of each other (the two directions of a cascade
-        cross layer, transformer.py:549), no rel_pos, no index output: one layout launch, one attention launch on the doubled batch ->
-        list of messages."""
+        cross layer, transformer.py:549), no rel_pos, no index output: one layout launch, one attention launch on the doubled batch
+        (split_attn: one attention launch per call) -> list of messages."""
         q0, k0 = calls[0][0], calls[0][1]
         hw_q, hw_k = tuple(q0.shape[2:]), tuple(k0.shape[2:])
         import os
@@ -487,6 +487,9 @@ class CascadeQTAttB(nn.Module):
             return [self.forward(q, k, v, tp, None, want_idx=False)[0] for q, k, v, tp in calls]
         B = q0.shape[0]
         qm = ops.nchw_to_quads_grouped([[c[j].float() for c in calls] for j in range(3)])
+        if split_attn:   # one layout launch for both directions, the attention per direction on its half of the operands
+            return [ops.cascade_attn_quad(qm[0][g * B:(g + 1) * B], qm[1][g * B:(g + 1) * B], qm[2][g * B:(g + 1) * B], c[3].contiguous(),
+                                          hw_q, hw_k, self.nhead, None) for g, c in enumerate(calls)]
         tp = torch.cat([c[3].contiguous() for c in calls], 0)
         msg = ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, hw_q, hw_k, self.nhead, None)
         return [msg[g * B:(g + 1) * B] for g in range(len(calls))]

@@ -275,9 +275,11 @@ class HotPath(torch.nn.Module):
                     blk = self.cascade_blocks[si][layer]
                     m0, i01 = blk(inp[f"{lvl}x0"], inp[f"{lvl}x1"], h, w, idx=tp01, rel_pos=rel01, want_idx=want_idx)
                     m1, i10 = blk(inp[f"{lvl}x1"], inp[f"{lvl}x0"], h, w, idx=tp10, rel_pos=rel10, want_idx=want_idx)
-                elif cfg.paired_layers is True and not want_idx and rel01 is None and rel10 is None:
+                elif cfg.paired_layers is True and not want_idx and rel01 is None and rel10 is None:   # ("coarse": a grouped layout pass
+                    # with one attention launch per direction, forward_multi(split_attn=True), measured no different: 12.21 ms either way)
                     m0, m1 = self.cascade_qta[si].forward_multi([(inp[f"{lvl}q0"][li], inp[f"{lvl}k1"][li], inp[f"{lvl}v1"][li], tp01),
-                                                                 (inp[f"{lvl}q1"][li], inp[f"{lvl}k0"][li], inp[f"{lvl}v0"][li], tp10)])
+                                                                 (inp[f"{lvl}q1"][li], inp[f"{lvl}k0"][li], inp[f"{lvl}v0"][li], tp10)],
+                                                                split_attn=False)
                     i01 = i10 = None
                 else:
                     att = self.cascade_qta[si]

@@ -47,8 +47,9 @@ def test_cascade_forward_multi_equals_separate_calls():
     with torch.no_grad():
         sep = [att(q, k, v, tp, None, want_idx=False)[0] for q, k, v, tp in calls]
         both = att.forward_multi(calls)
-    for a, b in zip(sep, both):
-        assert torch.equal(a, b)
+        hybrid = att.forward_multi(calls, split_attn=True)
+    for a, b, c in zip(sep, both, hybrid):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_grouped_layout_equals_single():
