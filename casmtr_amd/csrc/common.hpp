@@ -72,6 +72,18 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     const float d = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
     return (a + b) + (c + d);
 }
+
+// Softmax over a quad's window candidates (CascadeMatching.forward, cascade_matching.py:141), two candidates per lane: probabilities
+// from the hardware exponential (v_exp_f32 of (x - m) log2 e; x - m <= 0) and ONE exact division for 1 / sum -- within 2 ulp of
+// expf(x - m) / sum.  The probabilities carry the 1e-4 softmax tolerance and no index depends on them (the argmax is taken from the
+// logits); the three window-matching kernels share this function so that their outputs stay bit-equal to each other.
+__device__ __forceinline__ void window_softmax2(float x0, float x1, float m, bool v0, bool v1, float& e0, float& e1) {
+    e0 = v0 ? __expf(x0 - m) : 0.f;
+    e1 = v1 ? __expf(x1 - m) : 0.f;
+    const float inv = 1.0f / wave_sum_f32(e0 + e1);
+    e0 *= inv;
+    e1 *= inv;
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
     return ord2f(wave_max_u32(f2ord(v)));
 }

@@ -592,10 +592,8 @@ __global__ __launch_bounds__(256) void window_match_kernel(const float* __restri
     }
     const unsigned wm = wave_max_u32(max(key[0], key[1]));
     const float m = ord2f(wm);
-    float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
-    float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
-    const float s = wave_sum_f32(e0 + e1);
-    e0 = e0 / s; e1 = e1 / s;
+    float e0, e1;
+    window_softmax2(x[0], x[1], m, lane < K, 64 + lane < K, e0, e1);
     if (conf) {
         if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
         if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;
@@ -736,10 +734,8 @@ __global__ __launch_bounds__(256) void window_match_quad_kernel(const float* __r
         }
         const unsigned wm = wave_max_u32(max(key[0], key[1]));
         const float m = ord2f(wm);
-        float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
-        float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
-        const float sm = wave_sum_f32(e0 + e1);
-        e0 = e0 / sm; e1 = e1 / sm;
+        float e0, e1;
+        window_softmax2(x[0], x[1], m, lane < K, 64 + lane < K, e0, e1);
         if (conf) {
             if (lane < K) conf[((size_t)b * N + n) * K + lane] = e0;
             if (64 + lane < K) conf[((size_t)b * N + n) * K + 64 + lane] = e1;

@@ -15,7 +15,7 @@
 // ascending, result scaled by 1/T, masked entries -1e9, argmax = first maximum of the logits.
 #include <stdlib.h>
 #include <string.h>
-#include "common.hpp"
+#include "quad_common.hpp"
 #include "../../include/casmtr_hip.h"
 
 using namespace casmtr;
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
     float* __restrict__ conf, float* __restrict__ next_conf, int64_t* __restrict__ next_idx, int B, int h0, int w0, int h1, int w1,
     int KW, int dil, int nquads, int dbg) {
     constexpr int NCH = C / 32, NPASS = NP1 > 0 ? 2 : 1, NS = NCH * NPASS;
+    // sqrt(C) a power of two (C = 16, 64, 256): x / sqrt(C) is exact, so (q / sqrt(C)) * (k / sqrt(C)) == (q / C) * k as real numbers and the
+    // fmaf chain over them is bit-identical; the key rows are then used as they arrive (32 multiplications per stage and lane saved)
+    constexpr bool P2 = C == 16 || C == 64 || C == 256;
     constexpr int QV = (C + 255) / 256;                        // float4s of a child's query row per lane
     constexpr int QS = C + 4;                                 // query row stride: the 4 children's rows (broadcast reads, lane % 4) in different banks
     constexpr int WAVE_FLOATS = 4 * QS + 2 * 64 + 2 * 2048;  // queries [4][QS] | window positions [parity][32][2] | 2 x [64 rows][32]
@@ -67,7 +70,12 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
     if (t0 >= total) return;
     const unsigned buf_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(buf));
     const int sl = lane >> 3, un = lane & 7;
-    const unsigned swz[2] = {(unsigned)((un ^ (lane >> 4)) * 16), (unsigned)((un ^ (4 + (lane >> 4))) * 16)};   // DMA instr j even / odd
+    // DMA instruction j of a stage: 8 candidate rows (row 8 j + lane / 8, 16-byte unit `un` of the 128-byte channel chunk <- logical unit
+    // un ^ ((row >> 1) & 7)); four instructions share one M0 write (quad_common.hpp: the immediate offset advances the LDS destination AND
+    // the source, so instruction j % 4 is pre-biased by 3072 - 1024 (j % 4) against a base pointer that is 3072 bytes low)
+    unsigned swzb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) swzb[j] = (unsigned)((un ^ (((j & 1) * 4 + (lane >> 4)) & 7)) * 16) + 3072u - 1024u * j;
     unsigned rd[8];   // read side: byte offset of logical unit u in this lane's row
 #pragma unroll
     for (int u = 0; u < 8; ++u) rd[u] = (unsigned)(lane * 128 + ((u ^ ((lane >> 1) & 7)) * 16));
@@ -122,33 +130,41 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
     };
     auto stage_in = [&](const Item& it, int par) {
         int* pt = ptab + par * 64;
-        if (lane < KW) { pt[2 * lane] = (int)pf_y; pt[2 * lane + 1] = (int)pf_x; }
+        if (lane < KW) pt[lane] = ((int)pf_y * 2) * w1 + (int)pf_x * 2;   // first child of window cell `lane` on the fine grid (fits 32 bits)
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
             for (int i = 0; i < QV; ++i) {   // pre-scaled queries wait in registers until the current quad's last stage has read qn
                 f32x4 v = pf_q[f][i];
-                v.x = div_scalar<RECIP>(v.x, sqrtC, inv_sqrtC); v.y = div_scalar<RECIP>(v.y, sqrtC, inv_sqrtC);
-                v.z = div_scalar<RECIP>(v.z, sqrtC, inv_sqrtC); v.w = div_scalar<RECIP>(v.w, sqrtC, inv_sqrtC);
+                if constexpr (P2) {
+                    const float inv_C = inv_sqrtC * inv_sqrtC;   // exact: a power of two
+                    v.x *= inv_C; v.y *= inv_C; v.z *= inv_C; v.w *= inv_C;
+                } else {
+                    v.x = div_scalar<RECIP>(v.x, sqrtC, inv_sqrtC); v.y = div_scalar<RECIP>(v.y, sqrtC, inv_sqrtC);
+                    v.z = div_scalar<RECIP>(v.z, sqrtC, inv_sqrtC); v.w = div_scalar<RECIP>(v.w, sqrtC, inv_sqrtC);
+                }
                 q_nx[f][i] = v;
             }
         mq_nx = pf_mq;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // candidate k: parent e = k / 4 (window cell), child c = k % 4 -> (row + c/2 * dil, col + c%2 * dil), clamped (:419-429)
+        // candidate k: parent e = k / 4 (window cell), child c = k % 4 -> (row + c/2 * dil, col + c%2 * dil), clamped (:419-429); lists are
+        // padded with their last candidate.  This lane's own candidates are k = lane and 64 + lane ...
+        const int coff = (((lane & 3) >> 1) * w1 + (lane & 1)) * dil, coff3 = (w1 + 1) * dil;
         auto candidate = [&](int k) {
-            const int kk = k < K ? k : K - 1;
-            const int e = kk >> 2, c = kk & 3;
-            const int id = (pt[2 * e] * 2 + (c >> 1) * dil) * w1 + pt[2 * e + 1] * 2 + (c & 1) * dil;   // grid coordinates: fits 32 bits
+            const int id = pt[min(k >> 2, KW - 1)] + (k < K ? coff : coff3);
             return id < 0 ? 0 : (id > S - 1 ? S - 1 : id);
         };
+        cnd_nx[0] = candidate(lane);
+        cnd_nx[1] = candidate(64 + lane);
+        // ... and row 8 j + lane / 8 of a DMA instruction is the candidate of lane 8 j + lane / 8: one cross-lane read per instruction
+        const int rb[2] = {cnd_nx[0] * (C * 4), cnd_nx[1] * (C * 4)};
 #pragma unroll
         for (int p = 0; p < NPASS; ++p)
 #pragma unroll
-            for (int j = 0; j < (p == 0 ? 8 : NP1); ++j) rowb[p][j] = (unsigned)candidate(64 * p + 8 * j + sl) * (C * 4);
-        cnd_nx[0] = candidate(lane);
-        cnd_nx[1] = candidate(64 + lane);
+            for (int j = 0; j < (p == 0 ? 8 : NP1); ++j)
+                rowb[p][j] = (unsigned)__builtin_amdgcn_ds_bpermute((8 * j + sl) * 4, rb[p]) + swzb[j & 3];
         if (mq) {
             mk_nx[0] = mk[(size_t)it.b * S + cnd_nx[0]];
             mk_nx[1] = mk[(size_t)it.b * S + cnd_nx[1]];
@@ -157,10 +173,14 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
     auto issue = [&](auto sc, int b) {
         constexpr int s = decltype(sc)::value;
         constexpr int ch = s / NPASS, p = s % NPASS;
-        const float* base = fk + (size_t)b * S * C + ch * 32;   // wave-uniform: scalar arithmetic
-#pragma unroll
-        for (int j = 0; j < (p == 0 ? 8 : NP1); ++j)
-            glds16(base, rowb[p][j] + swz[j & 1], buf_lds + (unsigned)((s & 1) * 8192 + j * 1024));
+        const float* base = fk + (size_t)b * S * C + ch * 32 - 768;   // wave-uniform: scalar arithmetic; 3072 bytes low (swzb)
+        constexpr int NJ = p == 0 ? 8 : NP1;
+        const unsigned dst = buf_lds + (unsigned)((s & 1) * 8192);
+        if constexpr (NJ >= 4) glds_chunk(base, rowb[p][0], rowb[p][1], rowb[p][2], rowb[p][3], dst);
+        if constexpr (NJ == 8) glds_chunk(base, rowb[p][4], rowb[p][5], rowb[p][6], rowb[p][7], dst + 4096);
+        if constexpr (NJ % 4 == 1) glds_chunk1(base, rowb[p][NJ - 1], dst + (unsigned)((NJ - 1) * 1024));
+        if constexpr (NJ % 4 == 2) glds_chunk2(base, rowb[p][NJ - 2], rowb[p][NJ - 1], dst + (unsigned)((NJ - 2) * 1024));
+        if constexpr (NJ % 4 == 3) glds_chunk3(base, rowb[p][NJ - 3], rowb[p][NJ - 2], rowb[p][NJ - 1], dst + (unsigned)((NJ - 3) * 1024));
     };
     // results of the previous quad, stored one stage late (right behind a DMA wait: vmcnt counts stores too, in order)
     float pe[4][2] = {}, pnc[4] = {};
@@ -230,10 +250,12 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(bp + rd[u]);
             lds_reads_done();
+            if constexpr (!P2) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                kr[u].x = div_scalar<RECIP>(kr[u].x, sqrtC, inv_sqrtC); kr[u].y = div_scalar<RECIP>(kr[u].y, sqrtC, inv_sqrtC);
-                kr[u].z = div_scalar<RECIP>(kr[u].z, sqrtC, inv_sqrtC); kr[u].w = div_scalar<RECIP>(kr[u].w, sqrtC, inv_sqrtC);
+                for (int u = 0; u < 8; ++u) {
+                    kr[u].x = div_scalar<RECIP>(kr[u].x, sqrtC, inv_sqrtC); kr[u].y = div_scalar<RECIP>(kr[u].y, sqrtC, inv_sqrtC);
+                    kr[u].z = div_scalar<RECIP>(kr[u].z, sqrtC, inv_sqrtC); kr[u].w = div_scalar<RECIP>(kr[u].w, sqrtC, inv_sqrtC);
+                }
             }
             f32x4 a = acc[p];
 #pragma unroll
@@ -264,10 +286,8 @@ __global__ __launch_bounds__(128, 2) void window_match_pos_kernel(
                 }
                 const unsigned wm = wave_max_u32(max(key[0], key[1]));
                 const float m = ord2f(wm);
-                float e0 = (lane < K) ? expf(x[0] - m) : 0.f;
-                float e1 = (64 + lane < K) ? expf(x[1] - m) : 0.f;
-                const float sm = wave_sum_f32(e0 + e1);
-                e0 = e0 / sm; e1 = e1 / sm;
+                float e0, e1;
+                window_softmax2(x[0], x[1], m, lane < K, 64 + lane < K, e0, e1);
                 const unsigned long long b0 = __ballot(key[0] == wm && lane < K);
                 const unsigned long long b1 = __ballot(key[1] == wm && 64 + lane < K);
                 const int am = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
