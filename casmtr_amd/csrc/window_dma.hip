@@ -25,6 +25,11 @@ int casmtr_window_match_quad_pos(const float* fq, const float* fk, const int64_t
                                  int recip, float* conf, float* next_conf, int64_t* next_idx, int B, int h0, int w0, int h1, int w1,
                                  int KW, int C, int dil, hipStream_t s);
 
+// window_pair.hip: two quads per work item on a shared window box; CASMTR_ERR_UNSUPPORTED for shapes it does not cover
+int casmtr_window_match_pair(const float* fq, const float* fk, const int64_t* tp, const uint8_t* mq, const uint8_t* mk, float T, int recip,
+                             float* conf, float* next_conf, int64_t* next_idx, int B, int h0, int w0, int h1, int w1, int KW, int C, int dil,
+                             hipStream_t s);
+
 // candidate k of a quad: parent e = k / 4 (window cell), child t = k % 4 -> (row + t/2 * dil, col + t%2 * dil) on the fine grid,
 // clamped like torch.clamp at modules/quadtree_attention.py:429
 __device__ __forceinline__ int window_candidate(const int64_t* __restrict__ pos, int k, int K, int w1, int S, int dil) {
@@ -347,6 +352,11 @@ extern "C" int casmtr_window_match_pos_fwd(const float* feat_q, const float* fea
     if (ev && !strcmp(ev, "quad"))
         return casmtr_window_match_quad_pos(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx,
                                             B, h0, w0, h1, w1, KW, C, dilated, s);
+    if (!(ev && !strcmp(ev, "dma"))) {   // default: quad pairs on shared window boxes (window_pair.hip) where the shape allows it
+        const int r = casmtr_window_match_pair(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx, B, h0,
+                                               w0, h1, w1, KW, C, dilated, s);
+        if (r != CASMTR_ERR_UNSUPPORTED) return r;
+    }
 #define WM_CASE(CC)                                                                                                              \
     if (C == CC)                                                                                                                 \
         return recip ? dispatch_wm_pos_k<CC, true>(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, conf, next_conf,      \

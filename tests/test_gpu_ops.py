@@ -526,14 +526,15 @@ def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
         assert_close(N(out2["acc"]), o[0] * np.float32(0.5), SOFTMAX_TOL, "message * 0.5")
 
 
-@pytest.mark.parametrize("kernel", ["quad", "dma"])
+@pytest.mark.parametrize("kernel", ["quad", "dma", "pair"])
 @pytest.mark.parametrize("recip", [False, True])
 @pytest.mark.parametrize("C,ws,masks,dil", [(128, 5, False, 1), (128, 5, True, 1), (64, 5, False, 1), (128, 3, False, 1),
                                             (256, 5, False, 1), (32, 5, True, 2)])
 def test_window_match_implicit_windows(ops, monkeypatch, C, ws, masks, dil, recip, kernel):
     """casmtr_window_match_pos_fwd (topk_pos in, candidates expanded in-kernel, LDS-DMA key staging) == the explicit-index
     kernel == the oracle on the expanded tensor; casmtr_window_expand_idx == CascadeQTAttB's upsampled_idx."""
-    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", kernel)   # round-1 wave-per-quad kernel | default persistent LDS-DMA + MFMA kernel
+    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", kernel)   # round-1 wave-per-quad kernel | persistent LDS-DMA + MFMA kernel, one quad per item |
+                                                         # default: quad pairs on shared window boxes where the shape allows it
     B, hc, wc = 2, 12, 16
     h, w = 2 * hc, 2 * wc
     r = np.random.default_rng(100 + C + ws)
@@ -560,6 +561,43 @@ def test_window_match_implicit_windows(ops, monkeypatch, C, ws, masks, dil, reci
     assert_close(N(d["next_conf"]), o["next_conf"], SOFTMAX_TOL, "next_conf")
     n = ops.window_match(T(fq), T(fk), wi, 1.0, want_conf=False, **kw)
     assert n["conf_matrix"] is None and torch.equal(n["next_idx"], d["next_idx"])
+
+
+@pytest.mark.parametrize("C,hc,wc,masks,conf", [(128, 14, 16, False, True), (128, 13, 15, True, True), (64, 16, 21, False, True), (64, 12, 12, True, False)])
+def test_window_match_pair_kernel(ops, monkeypatch, C, hc, wc, masks, conf):
+    """window_match_pair_kernel (two quads per item on a shared 5 x 5 / 5 x 6 box) == window_match_pos_kernel (one quad per item) bit for
+    bit, == the oracle's argmax, on windows that follow a smooth coarse match field (most pairs share a box), with jumps, an irregular
+    position list and an odd number of quads per row (the last quad of a row runs alone)."""
+    B = 2
+    h, w = 2 * hc, 2 * wc
+    r = np.random.default_rng(7 + C + hc)
+    yy, xx = np.meshgrid(np.arange(hc), np.arange(wc), indexing="ij")
+    cidx = np.stack([np.clip(yy + 1 + (xx > wc // 2), 0, hc - 1) * wc + np.clip(xx - 2 + yy // 5, 0, wc - 1),      # smooth with steps
+                     np.where(r.random((hc, wc)) < 0.15, r.integers(0, hc * wc, (hc, wc)), (hc - 1 - yy) * wc + xx)]).reshape(B, hc * wc).astype(np.int64)
+    tp = ops.window_warp_idx(T(cidx), hc, wc, 5)
+    tp[0, 5, 7, 1] += 1                                   # one irregular list: that quad (and its neighbour) run as single sub-items
+    tp[1, 3, :, 0] = tp[1, 3, :, 0].flip(0)
+    wi = ops.WindowIndex(tp.contiguous(), (h, w), (h, w), 1)
+    fq = 2.0 * r.standard_normal((B, h * w, C), dtype=np.float32)
+    fk = fq + 0.7 * r.standard_normal((B, h * w, C), dtype=np.float32)
+    mq = mk = None
+    if masks:
+        mq = (r.random((B, h * w)) > 0.2).astype(np.uint8)
+        mk = (r.random((B, h * w)) > 0.2).astype(np.uint8)
+        mq[0, :40] = 0
+    kw = dict(mask_q=None if mq is None else T(mq), mask_k=None if mk is None else T(mk), recip=True, want_conf=conf)
+    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", "pair")
+    d = ops.window_match(T(fq), T(fk), wi, 1.0, **kw)
+    monkeypatch.setenv("CASMTR_WINDOW_KERNEL", "dma")
+    e = ops.window_match(T(fq), T(fk), wi, 1.0, **kw)
+    assert torch.equal(d["next_idx"], e["next_idx"]) and torch.equal(d["next_conf"], e["next_conf"])
+    if conf:
+        assert torch.equal(d["conf_matrix"], e["conf_matrix"])
+    else:
+        assert d["conf_matrix"] is None
+    o = oracle.window_match(fq, fk, N(wi.materialize()), 1.0, mq, mk, recip=True)
+    assert np.array_equal(N(d["next_idx"]), o["next_idx"]), "argmax must be bit-exact vs the oracle"
+    assert_close(N(d["next_conf"]), o["next_conf"], SOFTMAX_TOL, "next_conf")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = {"fine_quad.hip": (("fine_quad_kernel", 8),), "cascade_quad.hip": (("cascade_quad_kernel", 2),),
-         "coarse_tile.hip": (("coarse_tile_kernel", 10),)}
+         "coarse_tile.hip": (("coarse_tile_kernel", 10),), "window_pair.hip": (("window_match_pair_kernel", 2),)}
 NO_COMPILER_VMEM = {"fine_quad_kernel"}          # no vector load / vmcnt wait outside the inline-asm blocks
 SPILL_EXEMPT = re.compile(r"coarse_tile_kernelILi16E")   # S > 704 keys: 144 VGPRs at 3 waves per SIMD, spill-free today but not promised
 
