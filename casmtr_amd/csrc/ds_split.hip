@@ -443,32 +443,50 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
             const float m = mv[k];
             unsigned long long bal = __ballot(ok && tJ < NJB && m >= lim && m != NEG_FILL);
             while (bal) {
-                const int l = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                const int r = g * 64 + l;
-                const float rm_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), l));
-                const float rt_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rt), l));
-                const float tau_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tau), l));
-                const float rinv_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv), l));
-                const size_t o = (size_t)b * L + r;
-                const float* p = sim + o * S;
+                // up to four flagged segments per round: their 2 x 256-byte reads are all in flight before the first is looked at (a
+                // wave meets ~9 flagged segments; one dependent HBM round trip each was what the kernel's 150 us consisted of)
+                int ls[4], nl = 0;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int j = tJ * DS_BN + lane + 64 * u;
-                    if (j >= S) continue;
-                    const float x = p[j];
-                    if (x == NEG_FILL) continue;
-                    if (x >= rt_l) {
-                        const int slot = atomicAdd(w.rcnt + o, 1);
-                        if (slot < DS_CAND_CAP) w.rcand[o * DS_CAND_CAP + slot] = j; else *w.ovf = 1;
+                for (int q = 0; q < 4; ++q) {
+                    if (bal) { ls[q] = __ffsll((long long)bal) - 1; bal &= bal - 1; ++nl; } else ls[q] = 0;
+                }
+                float xs[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* p = sim + ((size_t)b * L + g * 64 + ls[q]) * S;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = tJ * DS_BN + lane + 64 * u;
+                        xs[q][u] = (q < nl && j < S) ? p[j] : NEG_FILL;
                     }
-                    if (x > tau_l) {
-                        const size_t co = (size_t)b * S + j;
-                        const float cf = (__expf(x - w.cmax[co]) * (1.0f / w.csum[co])) * (__expf(x - rm_l) * rinv_l);
-                        if (cf >= 0.f) {
-                            const unsigned long long hi = (unsigned long long)__float_as_uint(cf) << 32;
-                            atomicMax(w.rbest + o, hi | (0xFFFFFFFFu - (unsigned)j));
-                            atomicMax(w.cbest + co, hi | (0xFFFFFFFFu - (unsigned)r));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= nl) break;   // wave-uniform
+                    const int l = ls[q];
+                    const int r = g * 64 + l;
+                    const float rm_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), l));
+                    const float rt_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rt), l));
+                    const float tau_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tau), l));
+                    const float rinv_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv), l));
+                    const size_t o = (size_t)b * L + r;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = tJ * DS_BN + lane + 64 * u;
+                        const float x = xs[q][u];
+                        if (x == NEG_FILL) continue;   // also: column out of range / no segment in this slot
+                        if (x >= rt_l) {
+                            const int slot = atomicAdd(w.rcnt + o, 1);
+                            if (slot < DS_CAND_CAP) w.rcand[o * DS_CAND_CAP + slot] = j; else *w.ovf = 1;
+                        }
+                        if (x > tau_l) {
+                            const size_t co = (size_t)b * S + j;
+                            const float cf = (__expf(x - w.cmax[co]) * (1.0f / w.csum[co])) * (__expf(x - rm_l) * rinv_l);
+                            if (cf >= 0.f) {
+                                const unsigned long long hi = (unsigned long long)__float_as_uint(cf) << 32;
+                                atomicMax(w.rbest + o, hi | (0xFFFFFFFFu - (unsigned)j));
+                                atomicMax(w.cbest + co, hi | (0xFFFFFFFFu - (unsigned)r));
+                            }
                         }
                     }
                 }
@@ -489,22 +507,42 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
             const int tI = t0 + k;
             const float m = mv[k];
             unsigned long long bal = __ballot(ok && tI < NIB && m >= ct && m != NEG_FILL);
-            while (bal) {
-                const int l = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                const int col = g * 64 + l;
-                const float ct_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ct), l));
-                const size_t co = (size_t)b * S + col;
+            while (bal) {   // four flagged column segments per round, their group maxima and then their entries in flight together
+                int ls[4], nl = 0;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    // row lane + 64 u of the block belongs to the 16-row group (wr = u, ti = lane >> 5, hi = (lane >> 2) & 1)
-                    const int i = tI * DS_BM + lane + 64 * u;
-                    const float gm = w.cg_m[(((size_t)b * NIB + tI) * 8 + u * 4 + (lane >> 5) * 2 + ((lane >> 2) & 1)) * S + col];
-                    if (i >= L || !(gm >= ct_l)) continue;
-                    const float x = sim[((size_t)b * L + i) * S + col];
-                    if (x == NEG_FILL || !(x >= ct_l)) continue;
-                    const int slot = atomicAdd(w.ccnt + co, 1);
-                    if (slot < DS_CAND_CAP) w.ccand[co * DS_CAND_CAP + slot] = i; else *w.ovf = 1;
+                for (int q = 0; q < 4; ++q) {
+                    if (bal) { ls[q] = __ffsll((long long)bal) - 1; bal &= bal - 1; ++nl; } else ls[q] = 0;
+                }
+                float gm[4][2], xs[4][2], ctl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = g * 64 + ls[q];
+                    ctl[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ct), ls[q]));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)   // row lane + 64 u of the block belongs to the 16-row group (wr = u, ti = lane >> 5, hi = (lane >> 2) & 1)
+                        gm[q][u] = q < nl ? w.cg_m[(((size_t)b * NIB + tI) * 8 + u * 4 + (lane >> 5) * 2 + ((lane >> 2) & 1)) * S + col] : NEG_FILL;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = g * 64 + ls[q];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int i = tI * DS_BM + lane + 64 * u;
+                        xs[q][u] = (q < nl && i < L && gm[q][u] >= ctl[q]) ? sim[((size_t)b * L + i) * S + col] : NEG_FILL;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= nl) break;   // wave-uniform
+                    const size_t co = (size_t)b * S + g * 64 + ls[q];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int i = tI * DS_BM + lane + 64 * u;
+                        const float x = xs[q][u];
+                        if (x == NEG_FILL || !(x >= ctl[q])) continue;
+                        const int slot = atomicAdd(w.ccnt + co, 1);
+                        if (slot < DS_CAND_CAP) w.ccand[co * DS_CAND_CAP + slot] = i; else *w.ovf = 1;
+                    }
                 }
             }
         }
