@@ -345,9 +345,10 @@ extern "C" int casmtr_window_match_pos_fwd(const float* feat_q, const float* fea
     if (KW <= 0 || 4 * KW > 128 || (h0 & 1) || (w0 & 1) || (mask_q == nullptr) != (mask_k == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // default: the persistent LDS-DMA + MFMA kernel of this file (0.46 ms per launch at 208x208, C = 128, B = 8);
-    // CASMTR_WINDOW_KERNEL=quad selects the round-1 wave-per-quad kernel (matching.hip) with the candidate list expanded from
-    // topk_pos in registers (0.55 ms).  Read per call: tests switch it.
+    // Per launch at 208x208, C = 128, B = 8: window_match_pair_kernel (window_pair.hip; the default for 5 x 5 windows, dilation 1,
+    // C = 64 / 128, reciprocal scaling) 0.30 ms; window_match_pos_kernel of this file (every other shape, CASMTR_WINDOW_KERNEL=dma) 0.37 ms;
+    // the round-1 wave-per-quad kernel (matching.hip, CASMTR_WINDOW_KERNEL=quad) 0.55 ms.  All three give the same bits.  The
+    // variable is read per call: tests switch it.
     const char* ev = getenv("CASMTR_WINDOW_KERNEL");
     if (ev && !strcmp(ev, "quad"))
         return casmtr_window_match_quad_pos(feat_q, feat_k, topk_pos, mask_q, mask_k, temperature, recip, conf, next_conf, next_idx,
