@@ -24,4 +24,10 @@ for st in cfg.stages:
         same = (a[..., 0] == b[..., 0]) & (a[..., 1] == b[..., 1])
         print(f"{cfg.name} stage {st.level} {d}: {share.float().mean().item():.3f} of the adjacent quad pairs can share a 5x6 box "
               f"({same.float().mean().item():.3f} have identical windows)")
+        # 2 x 2 blocks of quads whose four windows fit one 6 x 6 box (row and column origins within one cell of each other)
+        he, we = hp // 2 * 2, wp // 2 * 2
+        blk = o[:, :he, :we].reshape(o.shape[0], he // 2, 2, we // 2, 2, 2)
+        ry = blk[..., 0].amax(dim=(2, 4)) - blk[..., 0].amin(dim=(2, 4))
+        rx = blk[..., 1].amax(dim=(2, 4)) - blk[..., 1].amin(dim=(2, 4))
+        print(f"    2 x 2 quad blocks that fit one 6 x 6 box: {((ry <= 1) & (rx <= 1)).float().mean().item():.3f}")
     prev = st.level
