@@ -332,10 +332,12 @@ class RunAhead:
     The finalised lists are allocated from the side stream's pool and consumed on the launch stream (e.g. MatchGatherer's
     collectives).  They are NOT `record_stream`-ed: the allocator would record one event on the launch stream per tensor when it is
     freed (7 per step, 5.6 us of idle stream each: the 40 us hole at every step boundary in a rocprofv3 trace, tools/trace_gaps.py).
-    It is not needed either: a freed block is only ever reused by a LATER finalize on this private side stream, and every finalize
-    starts by waiting for an event recorded on the launch stream after everything the (single) host thread had enqueued there before
-    -- including every consumer of the block.  The host waits for the side stream before it returns, so nothing is freed while the
-    side stream still works on it."""
+    Instead every finalize waits for TWO launch-stream events: the end-of-step event of the step it finalises, and a "consumers"
+    event recorded at the START of the submit / drain that runs it, i.e. after everything the (single) host thread had enqueued on
+    the launch stream up to that call -- including every consumer of an earlier result whose blocks this finalize may be handed by
+    the side pool (a caller may drop a result right after enqueueing its consumer: `consume(ra.submit(x))`, MatchGatherer.flush).
+    The consumers event precedes the new step's kernels, so the wait costs no overlap.  The host waits for the side stream before
+    it returns, so nothing is freed while the side stream still works on it."""
 
     def __init__(self, model: "HotPath"):
         self.model = model
@@ -344,23 +346,28 @@ class RunAhead:
 
     def submit(self, inp):
         """-> finalised output of the PREVIOUS submit (None on the first call)"""
+        consumers = torch.cuda.Event()
+        consumers.record()   # launch stream, BEFORE the new step: covers every consumer of earlier results enqueued so far
         new = self.model(inp, finalize=False)
         ev = torch.cuda.Event()
         ev.record()
         old, self.pend = self.pend, (new, ev)
-        return self._finish(old)
+        return self._finish(old, consumers)
 
     def drain(self):
         """-> finalised output of the last submit (None if there is none)"""
+        consumers = torch.cuda.Event()
+        consumers.record()
         old, self.pend = self.pend, None
-        return self._finish(old)
+        return self._finish(old, consumers)
 
-    def _finish(self, old):
+    def _finish(self, old, consumers):
         if old is None:
             return None
         out, ev = old
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
+            self.side.wait_event(consumers)
             res = self.model.finalize(out)
         # Everything the side stream read (step k's buffers, owned by the launch stream's pool) must be done before those buffers
         # can be dropped; the tail after finalize's last sync is a handful of gathers.

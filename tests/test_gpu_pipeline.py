@@ -579,3 +579,43 @@ def test_run_ahead_side_stream_finalize_equals_eager():
             assert torch.equal(o[k], ref[k]), (i, k)
         for k in ref8:
             assert torch.equal(o["data"]["stage_8c"][k], ref8[k]), (i, k)
+
+
+def test_run_ahead_results_dropped_behind_a_slow_consumer():
+    """a caller may drop a finalised result right after enqueueing its launch-stream consumer
+    (`consume(ra.submit(x))`, MatchGatherer.flush).  The lists live in the side stream's pool and are not record_stream-ed, so the
+    NEXT finalize must not start before that consumer has run: RunAhead makes it wait for a launch-stream event recorded at the
+    start of the submit that runs it.  Here every consumer sits behind ~10 ms of unrelated launch-stream work and the result is
+    dropped at once; with the missing wait the following finalize rewrote the lists first."""
+    from casmtr_amd.pipeline import HotPath, HotPathConfig, RunAhead, make_synthetic_inputs
+    cfg = HotPathConfig(name="small", image_hw=(256, 320), coarse_layers=2)
+    model = HotPath(cfg).to(DEV)
+    inps = [make_synthetic_inputs(cfg, 2, DEV, seed=s) for s in (7, 8)]
+    with torch.no_grad():
+        model.qta.weight.copy_(inps[0]["weight"])
+    keys = ("mkpts0", "mkpts1", "mconf")
+    want = []
+    for inp in inps:
+        r = model(inp)
+        want.append(torch.stack([r[k].double().sum() for k in keys]))
+    assert not torch.equal(want[0], want[1])
+    big = torch.randn(4096, 4096, device=DEV)
+    ra = RunAhead(model)
+    sums = []
+
+    def consume(res):
+        if res is None:
+            return
+        x = big
+        for _ in range(6):   # ~10 ms of launch-stream work in front of the consumer
+            x = x @ big
+        s = torch.stack([res[k].double().sum() for k in keys]) + 0.0 * x[0, 0].double()
+        sums.append(s)       # the result itself goes out of scope here
+
+    for i in range(16):
+        consume(ra.submit(inps[i & 1]))
+    consume(ra.drain())
+    torch.cuda.synchronize()
+    assert len(sums) == 16
+    for i, s in enumerate(sums):
+        assert torch.equal(s, want[i & 1]), (i, s, want[i & 1])
