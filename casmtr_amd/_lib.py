@@ -62,6 +62,8 @@ SIGNATURES = {
     "casmtr_prof_reserve": (_I, [_I]),
     "casmtr_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "casmtr_prof_name": (C.c_char_p, [_I]),
+    "casmtr_prof_symbol": (C.c_char_p, [_I]),
+    "casmtr_prof_read_all": (_I, [_I, C.POINTER(C.c_double), _I]),
 }
 PROF_COUNT = 20
 
@@ -81,8 +83,30 @@ def prof_reserve(pairs: int):
     check(lib().casmtr_prof_reserve(int(pairs)), "prof_reserve")
 
 
+def prof_symbols():
+    """-> {scope name: kernel symbol(s) that ran under it since it was last timed}"""
+    out = {}
+    for i in range(PROF_COUNT):
+        s = lib().casmtr_prof_symbol(i).decode()
+        if s:
+            out[lib().casmtr_prof_name(i).decode()] = s
+    return out
+
+
+def prof_read_all(name: str):
+    """-> the individual launch durations (ms) of scope `name`, in launch order"""
+    ids = {lib().casmtr_prof_name(i).decode(): i for i in range(PROF_COUNT)}
+    n = lib().casmtr_prof_read_all(ids[name], None, 0)
+    if n <= 0:
+        return []
+    buf = (C.c_double * n)()
+    if lib().casmtr_prof_read_all(ids[name], buf, n) != n:
+        raise RuntimeError("prof_read_all")
+    return list(buf)
+
+
 def prof_read():
-    """-> {kernel name: (total_ms, launches)} for every kernel launched since prof_enable(True)."""
+    """-> {scope name: (total_ms, launches)} for every scope timed since prof_enable(True)."""
     out = {}
     for i in range(PROF_COUNT):
         ms, n = C.c_double(0.0), C.c_int(0)
@@ -118,7 +142,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if l.casmtr_abi_version() != 4:
+        if l.casmtr_abi_version() != 5:
             raise RuntimeError("libcasmtr_hip.so ABI version mismatch")
         _lib = l
     return _lib

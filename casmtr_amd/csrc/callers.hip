@@ -149,7 +149,7 @@ extern "C" int casmtr_token_pool_fwd(const float* const* src, float* const* dst,
     PoolBatch pb{};
     for (int i = 0; i < n; ++i) { pb.src[i] = src[i]; pb.dst[i] = dst[i]; }
     const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
-    ProfScope ps(CASMTR_PROF_TOKEN_POOL, (hipStream_t)stream);
+    ProfScope ps(CASMTR_PROF_TOKEN_POOL, (hipStream_t)stream, "token_pool_kernel");
     hipLaunchKernelGGL(token_pool_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, pb,
                        H, W, C / 4, total);
     CASMTR_CHECK_LAUNCH();

@@ -261,7 +261,7 @@ static int launch_cas(const float* q, const float* key, const float* value, cons
     const long long work = (long long)B * nquads;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
-    ProfScope ps(CASMTR_PROF_CASCADE_ATTN, s);
+    ProfScope ps(CASMTR_PROF_CASCADE_ATTN, s, "cascade_attn_dma_kernel");
     if (rel)
         hipLaunchKernelGGL((cascade_attn_dma_kernel<H, NP1, true>), dim3((unsigned)blocks), dim3(128), lds, s, q, key, value, tp, rel,
                            message, up_idx, temp, dil, B, h0, w0, h1, w1, KW, nquads, g_debug_flags);

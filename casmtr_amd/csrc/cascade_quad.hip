@@ -426,6 +426,7 @@ static int launch_cas_quad(const CasQArgs& a, hipStream_t s) {
     if (wpx > per_pair * a.B) wpx = per_pair * a.B;
     const long long blocks = (wpx + 1) / 2 * 8;
     if (getenv("CASMTR_FQ_DEBUG")) fprintf(stderr, "cascade_quad<%d>: %zu B LDS per workgroup, %d resident workgroups, launching %lld\n", (int)HAS_REL, lds, res, blocks);
+    prof_symbol_args(CASMTR_PROF_CASCADE_ATTN, "<%s>", HAS_REL ? "true" : "false");
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_CASCADE_ATTN, (cascade_quad_kernel<HAS_REL>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;

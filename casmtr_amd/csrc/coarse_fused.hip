@@ -252,7 +252,7 @@ int casmtr_qta_coarse_level_fused(const float* q, const float* k, const float* v
     if (E > 16 || S < 1) return CASMTR_ERR_UNSUPPORTED;
     const size_t lds = sizeof(float) * ((16 * (Spad + 2) > 2048 ? 16 * (Spad + 2) : 2048) + 4 * 128);
     const dim3 grid((L + 15) / 16, B * H);
-    ProfScope ps(CASMTR_PROF_COARSE_FUSED, s);
+    ProfScope ps(CASMTR_PROF_COARSE_FUSED, s, "coarse_fused_kernel");
 #define CF_CASE(EE)                                                                                                                     \
     if (E <= EE) {                                                                                                                      \
         if (lds > 48 * 1024)                                                                                                            \

@@ -439,6 +439,7 @@ int casmtr_qta_coarse_level_tile(const float* q, const float* k, const float* v,
         if (lds > 48 * 1024)                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_tile_kernel<EE, NWW, NSS>),                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+        prof_symbol_args(CASMTR_PROF_COARSE_FUSED, "<%d,%d,%d>", EE, NWW, NSS);                                                     \
         CASMTR_LAUNCH_TIMED(CASMTR_PROF_COARSE_FUSED, (coarse_tile_kernel<EE, NWW, NSS>), dim3(grid), dim3(64 * NWW), lds, s, a);    \
     }
 #define CT_CASE(EE)                                                  \

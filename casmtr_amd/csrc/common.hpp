@@ -210,17 +210,27 @@ void prof_end(int id, hipStream_t s);
 // timestamps and put no barrier packet on the stream.  (Events recorded around a launch cost 5.8 us of idle stream each: rocprofv3
 // kernel trace of the bench step, 24 records per step.)  prof_pair() -> false when kernel `id` is not being timed.
 bool prof_pair(int id, hipEvent_t* a, hipEvent_t* b);
+// Which kernel ran under scope `id` last (casmtr_prof_symbol): the instantiated symbol of a single-kernel scope, a literal list for
+// the multi-kernel scopes.  `sym` must have static storage duration.
+void prof_symbol(int id, const char* sym);
+// template arguments of the instantiation about to be launched under scope `id` (printf-style, e.g. "<%d,%d>"): replaces the
+// "<...>" of the stringified kernel expression CASMTR_LAUNCH_TIMED records.  No-op unless `id` is being timed.
+void prof_symbol_args(int id, const char* fmt, ...);
 #define CASMTR_LAUNCH_TIMED(id, kernel, grid, block, lds, stream, ...)                                          \
     do {                                                                                                       \
         hipEvent_t ea__, eb__;                                                                                 \
-        if (casmtr::prof_pair(id, &ea__, &eb__))                                                               \
+        if (casmtr::prof_pair(id, &ea__, &eb__)) {                                                             \
+            casmtr::prof_symbol(id, #kernel);                                         \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ea__, eb__, 0, __VA_ARGS__);               \
-        else                                                                                                   \
+        } else                                                                                                 \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
     } while (0)
 struct ProfScope {
     int id; hipStream_t s;
-    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
+    ProfScope(int id_, hipStream_t s_, const char* sym = nullptr) : id(id_), s(s_) {
+        prof_begin(id, s);
+        if (sym) prof_symbol(id, sym);
+    }
     ~ProfScope() { prof_end(id, s); }
 };
 

@@ -296,12 +296,12 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     if (tid < 128) {
         const int gi = tI * DS_BM + tid;
         const float f = fa[((size_t)b * NIB + tI) * 128 + tid];   // sign = padding mask (ds_rownorm_kernel)
-        masked = mask0 && gi < L && f < 0.f;
+        masked = mask0 && gi < L && __float_as_int(f) < 0;   // the SIGN BIT: -0.f (a row whose factor underflowed) is still masked
         facA[tid] = f;
     } else {
         const int gj = tJ * DS_BN + tid - 128;
         const float f = fb[((size_t)b * NJB + tJ) * 128 + tid - 128];
-        masked = mask0 && gj < S && f < 0.f;
+        masked = mask0 && gj < S && __float_as_int(f) < 0;
         facB[tid - 128] = f;
     }
     f32x16 acc[2][2];

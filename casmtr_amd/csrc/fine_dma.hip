@@ -334,7 +334,7 @@ static int launch_fine(const FineArgs& a, hipStream_t s) {
     const long long work = (long long)a.B * a.nquads * a.H;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
-    ProfScope ps(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, s);
+    ProfScope ps(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, s, "fine_level_dma_kernel");
     hipLaunchKernelGGL((fine_level_dma_kernel<NPASS, EXACT>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;

@@ -554,6 +554,7 @@ static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
     if (wpx > per_pair * a.B) wpx = per_pair * a.B;
     const long long blocks = (wpx + 1) / 2 * 8;
     if (getenv("CASMTR_FQ_DEBUG")) fprintf(stderr, "fine_quad<%d,%d>: %zu B LDS per workgroup, %d resident workgroups, launching %lld\n", NPASS, (int)EXACT, lds, res, blocks);
+    prof_symbol_args(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, "<%d,%s,%s>", NPASS, EXACT ? "true" : "false", FULL ? "true" : "false");
     CASMTR_LAUNCH_TIMED(NPASS == 1 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2, (fine_quad_kernel<NPASS, EXACT, FULL>), dim3((unsigned)blocks),
                         dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();

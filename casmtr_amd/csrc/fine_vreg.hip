@@ -311,7 +311,7 @@ static int launch_fine_vreg(const FineVArgs& a, hipStream_t s) {
     const long long work = (long long)a.B * a.nquads * a.H;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
-    ProfScope ps(CASMTR_PROF_QTA_FINE, s);
+    ProfScope ps(CASMTR_PROF_QTA_FINE, s, "fine_level_vreg_kernel");
     hipLaunchKernelGGL((fine_level_vreg_kernel<EXACT>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;

@@ -391,7 +391,7 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
     else
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds);
     {
-        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_GEMM, s);
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_GEMM, s, recip ? "ds_gemm_kernel<true>" : "ds_gemm_kernel<false>");
         const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
         const int gx = guard ? min(ntiles, 768) : ntiles;
         if (recip)
@@ -403,7 +403,7 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
     }
     CASMTR_CHECK_LAUNCH();
     {
-        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_REDUCE, s);
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel x2");
         hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L,
                            w.rmax, w.rsum, next_idx01, next_conf01, nullptr, 0, nullptr, 0.f, nullptr, guard);
         CASMTR_CHECK_LAUNCH();
@@ -417,7 +417,7 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
         CASMTR_CHECK_LAUNCH();
     }
     {
-        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_CONF, s);
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_CONF, s, "ds_conf_kernel<false>");
         hipLaunchKernelGGL(ds_conf_kernel<false>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
                            w, L, S, want_conf, thr, guard);
     }
@@ -428,7 +428,7 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
 static int ds_select(const DsWs& w, float thr, int border_rm, const int32_t* valid_hw, int h0c, int w0c, int h1c, int w1c,
                      int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mconf, int64_t* n_matches, int B, int L, int S,
                      hipStream_t s) {
-    ProfScope ps(CASMTR_PROF_DS_SELECT, s);
+    ProfScope ps(CASMTR_PROF_DS_SELECT, s, "ds_flag_kernel + compaction (count / scan / write)");
     hipLaunchKernelGGL(ds_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, thr, border_rm, valid_hw, h0c, w0c,
                        h1c, w1c, L, S, B * L);
     CASMTR_CHECK_LAUNCH();
@@ -483,7 +483,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     CASMTR_CHECK_LAUNCH();
     int rc;
     {
-        ProfScope ps(CASMTR_PROF_DS_SPLIT, s);
+        ProfScope ps(CASMTR_PROF_DS_SPLIT, s, "ds_rownorm_kernel x2 + ds_nmax_kernel + ds_split_kernel x2");
         rc = ds_split_launch(feat0, feat1, mask0, mask1, w, B, L, S, C, temperature, recip, s);
     }
     if (rc) return rc;
@@ -492,7 +492,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     }
     if (rc) return rc;
     {
-        ProfScope ps(CASMTR_PROF_DS_REDUCE, s);
+        ProfScope ps(CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel x2");
         const float kthr = 6.103515625e-05f / temperature;   // 2 e = 2^-14 |a_i|/sqrtC max|b_j|/sqrtC / T
         hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, nullptr, NJB, L, B * L,
                            w.rmax, w.rsum, next_idx01, next_conf01, w.na, NIB * DS_BM, w.nbmax, kthr, w.rthr, nullptr);
@@ -502,7 +502,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
         CASMTR_CHECK_LAUNCH();
     }
     {
-        ProfScope ps(CASMTR_PROF_DS_CONF, s);
+        ProfScope ps(CASMTR_PROF_DS_CONF, s, (!want_conf && thr >= 1e-3f) ? "ds_sparse_kernel (segment-sparse pass 2)" : "ds_conf_kernel<true>");
         if (!want_conf && thr >= 1e-3f) {   // segment-sparse pass 2 (the dense one is needed only to write conf_matrix)
             rc = ds_sparse_launch(sim_ws, w, B, L, S, thr, s);
             if (rc) return rc;
@@ -512,7 +512,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     }
     CASMTR_CHECK_LAUNCH();
     {
-        ProfScope ps(CASMTR_PROF_DS_FIX, s);
+        ProfScope ps(CASMTR_PROF_DS_FIX, s, "ds_fix_kernel + guarded exact-pass launches (exit at once unless a candidate list overflowed)");
         rc = ds_fix_launch(feat0, feat1, w, B, L, S, C, temperature, recip, next_idx01, next_idx10, s);
         if (rc) return rc;
         rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
@@ -755,7 +755,7 @@ static int launch_window_match_r(const float* fq, const float* fk, const int64_t
                                  float T, float* conf, float* next_conf, int64_t* next_idx, int B, int N, int M, int K, int h,
                                  int w, hipStream_t s) {
     const float sqrtC = (float)sqrt((double)C);
-    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
+    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s, "window_match_quad_kernel / window_match_kernel (explicit index list)");
     if (h > 0 && w > 0 && (h % 2 == 0) && (w % 2 == 0) && h * w == N) {
         const int nquads = (h / 2) * (w / 2);
         hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3((nquads + 3) / 4, B), dim3(256), sizeof(float) * 16 * C, s, fq,
@@ -800,7 +800,7 @@ static int launch_wm_quad_pos(const float* fq, const float* fk, const int64_t* t
                               int dil, hipStream_t s) {
     const float sqrtC = (float)sqrt((double)C);
     const int nquads = (h0 / 2) * (w0 / 2);
-    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s);
+    ProfScope ps(CASMTR_PROF_WINDOW_MATCH, s, "window_match_quad_kernel (implicit windows)");
     hipLaunchKernelGGL((window_match_quad_kernel<C, RECIP>), dim3((nquads + 3) / 4, B), dim3(256), sizeof(float) * 16 * C, s, fq, fk,
                        (const int64_t*)nullptr, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, h0 * w0, h1 * w1,
                        4 * KW, h0, w0, nquads, tp, w1, dil);
@@ -886,7 +886,7 @@ extern "C" int casmtr_nms_select_fwd(const float* next_conf01, const int64_t* ne
     const int total = B * H0 * W0;
     unsigned char* keep = reinterpret_cast<unsigned char*>(ws);
     int* blk = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align256((size_t)total));
-    ProfScope ps(CASMTR_PROF_NMS_SELECT, s);
+    ProfScope ps(CASMTR_PROF_NMS_SELECT, s, "nms_flag_kernel + compaction (count / scan / write)");
     hipLaunchKernelGGL(nms_flag_kernel, dim3((total + 255) / 256), dim3(256), 0, s, next_conf01, next_idx01, next_idx10,
                        nms_window, test_thr, pre_conf0, hp0, wp0, pre_thr0, pre_conf1, hp1, wp1, pre_thr1, border_rm,
                        valid_hw, double_check, keep, B, H0, W0, H1, W1, extra_keep);

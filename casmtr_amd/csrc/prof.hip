@@ -1,7 +1,10 @@
 // Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers).  Single-kernel scopes
 // (CASMTR_LAUNCH_TIMED, common.hpp) attach the event pair to the dispatch itself; scopes that span several launches (ProfScope) record
 // events around them.  Disabled by default: both are a branch on a global mask.
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "common.hpp"
 #include "../../include/casmtr_hip.h"
@@ -13,6 +16,27 @@ struct Pair { hipEvent_t a, b; };
 static std::vector<Pair> g_ev[CASMTR_PROF_COUNT];
 static std::vector<Pair> g_free;
 static Pair g_open[CASMTR_PROF_COUNT];
+static const char* g_sym[CASMTR_PROF_COUNT];
+
+static char g_sym_args[CASMTR_PROF_COUNT][96];
+static char g_sym_out[CASMTR_PROF_COUNT][192];
+
+static bool g_sym_fresh[CASMTR_PROF_COUNT];   // prof_symbol_args() was called for the launch that prof_symbol() now records
+
+void prof_symbol(int id, const char* sym) {
+    if (id < 0 || id >= CASMTR_PROF_COUNT || !(g_mask >> id & 1u)) return;
+    g_sym[id] = sym;
+    if (!g_sym_fresh[id]) g_sym_args[id][0] = 0;
+    g_sym_fresh[id] = false;
+}
+void prof_symbol_args(int id, const char* fmt, ...) {
+    if (id < 0 || id >= CASMTR_PROF_COUNT || !(g_mask >> id & 1u)) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_sym_args[id], sizeof g_sym_args[id], fmt, ap);
+    va_end(ap);
+    g_sym_fresh[id] = true;
+}
 
 // Timing-only events: no system-scope fence (L2 write-back + invalidate) when they are recorded; nothing reads device memory through
 // them.  Measured: the timed kernel 1 % shorter (195.8 against 197.6 us), the step 0.02 ms; the 5.8 us of idle stream that a rocprofv3
@@ -45,11 +69,13 @@ void prof_end(int id, hipStream_t s) {
 
 using namespace casmtr;
 
+// Scope names = stages of the path (several kernels can serve a stage, depending on shape and CASMTR_*_KERNEL selectors);
+// casmtr_prof_symbol() names the kernel that actually ran.
 static const char* kNames[CASMTR_PROF_COUNT] = {
-    "ds_gemm_kernel", "ds_reduce_kernel", "ds_conf_kernel", "ds_select", "coarse_logits_kernel", "coarse_row_kernel",
-    "coarse_av_kernel", "qta_fine_level[lists<=64]", "quad_attn_kernel<cascade>", "window_match_kernel", "nms_select",
-    "nchw_to_tokens_kernel", "window_warp_idx_kernel", "linear_nt_kernel", "token_pool_kernel", "coarse_fused_kernel",
-    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "ds_split_kernel", "ds_fix_kernel"};
+    "dual_softmax_gemm", "dual_softmax_reduce", "dual_softmax_pass2", "dual_softmax_select", "qta_coarsest[logits]", "qta_coarsest[row]",
+    "qta_coarsest[av]", "qta_fine_level[lists<=64]", "cascade_attn", "window_match", "nms_select",
+    "layout", "window_warp_idx", "linear_nt", "token_pool", "qta_coarsest_level",
+    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "dual_softmax_split_prepass", "dual_softmax_fix"};
 
 static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {
@@ -101,6 +127,37 @@ extern "C" int casmtr_prof_read(int id, double* total_ms, int* count) {
     *total_ms = tot;
     *count = (int)g_ev[id].size();
     return 0;
+}
+
+// durations (ms) of the individual launches of scope `id`, in launch order: writes min(count, cap) values, returns the count
+extern "C" int casmtr_prof_read_all(int id, double* ms_out, int cap) {
+    if (id < 0 || id >= CASMTR_PROF_COUNT) return -1;
+    int i = 0;
+    for (auto& p : g_ev[id]) {
+        if (i >= cap) break;
+        if (hipEventSynchronize(p.b) != hipSuccess) return -1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) return -1;
+        ms_out[i++] = ms;
+    }
+    return (int)g_ev[id].size();
+}
+
+extern "C" const char* casmtr_prof_symbol(int id) {
+    if (id < 0 || id >= CASMTR_PROF_COUNT || !g_sym[id]) return "";
+    // "(fine_quad_kernel<NPASS, EXACT, FULL>)" + recorded arguments "<1,0,1>" -> "fine_quad_kernel<1,0,1>"
+    const char* b = g_sym[id];
+    while (*b == '(') ++b;
+    size_t n = strcspn(b, "<)");
+    const bool templ = b[n] == '<';
+    if (n >= sizeof g_sym_out[id]) n = sizeof g_sym_out[id] - 1;
+    if (templ && g_sym_args[id][0]) snprintf(g_sym_out[id], sizeof g_sym_out[id], "%.*s%s", (int)n, b, g_sym_args[id]);
+    else {
+        size_t m = strcspn(b, ")");
+        if (strchr(b, ' ') && !templ) m = strlen(b);   // literal descriptions of the multi-kernel scopes stay as they are
+        snprintf(g_sym_out[id], sizeof g_sym_out[id], "%.*s", (int)m, b);
+    }
+    return g_sym_out[id];
 }
 
 extern "C" const char* casmtr_prof_name(int id) { return (id >= 0 && id < CASMTR_PROF_COUNT) ? kNames[id] : ""; }

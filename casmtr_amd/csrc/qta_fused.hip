@@ -102,7 +102,7 @@ extern "C" int casmtr_nchw_to_tokens_multi(const float* const* src, float* const
     }
     lb.tile_begin[n] = tiles;
     if (tiles == 0) return 0;
-    ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream);
+    ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream, "nchw_to_tokens_kernel");
     hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, lb);
     CASMTR_CHECK_LAUNCH();
     return 0;
@@ -408,7 +408,7 @@ static int launch_quad(const QuadArgs& a, int B, hipStream_t s) {
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quad_attn_kernel<H, KMAX, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    ProfScope ps(MODE == 0 ? (KMAX <= 64 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2) : CASMTR_PROF_CASCADE_ATTN, s);
+    ProfScope ps(MODE == 0 ? (KMAX <= 64 ? CASMTR_PROF_QTA_FINE : CASMTR_PROF_QTA_FINE2) : CASMTR_PROF_CASCADE_ATTN, s, "quad_attn_kernel (token-major)");
     hipLaunchKernelGGL((quad_attn_kernel<H, KMAX, MODE>), dim3(Lq * B), dim3(256), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;
@@ -782,10 +782,13 @@ extern "C" int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, c
         if (r == 0 && topk_tab) return casmtr_topk_idx_to_tab(topk_idx, topk_tab, B, L, topk, H, stream);
         if (r != CASMTR_ERR_UNSUPPORTED) return r;
     }
+    // casmtr_qta_coarse_level_ws_floats_k() promised a 1-float workspace for the tile / fused modes: if such a kernel still declines
+    // the shape (e.g. S * H * 128 >= 2^31 in the tile kernel) the three-kernel path below must NOT run on that dummy workspace
+    if (mode != COARSE_THREE) return CASMTR_ERR_UNSUPPORTED;
     if (!logits_ws || !topk_score || !topk_idx) return CASMTR_ERR_UNSUPPORTED;   // the three-kernel path needs its workspace and writes both lists
     const int Spad = (S + 63) / 64 * 64;
     {
-        ProfScope ps(CASMTR_PROF_COARSE_LOGITS, s);
+        ProfScope ps(CASMTR_PROF_COARSE_LOGITS, s, "coarse_logits_kernel");
         hipLaunchKernelGGL(coarse_logits_kernel, dim3(Spad / 64, (L + 63) / 64, B * H), dim3(256), 0, s, q, k, logits_ws,
                            temp, L, S, Spad, H);
     }
@@ -795,6 +798,7 @@ extern "C" int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, c
     const dim3 rg((rows + 3) / 4);
     const int E = Spad / 64;
     prof_begin(CASMTR_PROF_COARSE_ROW, s);
+    prof_symbol(CASMTR_PROF_COARSE_ROW, "coarse_row_kernel<E>");
     if (E <= 4)
         hipLaunchKernelGGL(coarse_row_kernel<4>, rg, dim3(256), 0, s, logits_ws, rowstat, topk_score, topk_idx, topk_tab, topk, B, L, S, Spad, H);
     else if (E <= 8)
@@ -810,7 +814,7 @@ extern "C" int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, c
     prof_end(CASMTR_PROF_COARSE_ROW, s);
     CASMTR_CHECK_LAUNCH();
     {
-        ProfScope ps(CASMTR_PROF_COARSE_AV, s);
+        ProfScope ps(CASMTR_PROF_COARSE_AV, s, "coarse_av_kernel");
         hipLaunchKernelGGL(coarse_av_kernel, dim3((L + 127) / 128, B * H), dim3(256), 0, s, logits_ws, rowstat, v, message, acc_out,
                            w_level, L, S, Spad, H);
     }
@@ -840,7 +844,7 @@ extern "C" int casmtr_window_warp_idx(const int64_t* idx, int64_t* out, int B, i
     if (total <= 0) return 0;
     long long blocks = (total * ws * ws + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    ProfScope ps(CASMTR_PROF_WINDOW_WARP, (hipStream_t)stream);
+    ProfScope ps(CASMTR_PROF_WINDOW_WARP, (hipStream_t)stream, "window_warp_idx_kernel");
     hipLaunchKernelGGL(window_warp_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, out, total,
                        H, W, ws);
     CASMTR_CHECK_LAUNCH();

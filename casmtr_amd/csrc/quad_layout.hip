@@ -158,7 +158,7 @@ extern "C" int casmtr_tokens_to_quads(const float* x, float* out, int B, int C, 
     if (total4 <= 0) return 0;
     long long blocks = (total4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream);
+    ProfScope ps(CASMTR_PROF_LAYOUT, (hipStream_t)stream, "tokens_to_quads_kernel");
     hipLaunchKernelGGL(tokens_to_quads_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, total4, C, h, w);
     CASMTR_CHECK_LAUNCH();
     return 0;

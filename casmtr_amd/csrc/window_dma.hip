@@ -322,6 +322,7 @@ static int launch_wm_pos(const float* fq, const float* fk, const int64_t* tp, co
     const long long work = (long long)B * nquads;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
+    prof_symbol_args(CASMTR_PROF_WINDOW_MATCH, "<%d,%s,%d>", C, RECIP ? "true" : "false", NP1);
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_WINDOW_MATCH, (window_match_pos_kernel<C, RECIP, NP1>), dim3((unsigned)blocks), dim3(128), lds, s, fq, fk,
                         tp, mq, mk, sqrtC, 1.0f / sqrtC, T, 1.0f / T, conf, next_conf, next_idx, B, h0, w0, h1, w1, KW, dil, nquads, g_debug_flags);
     CASMTR_CHECK_LAUNCH();
@@ -392,7 +393,7 @@ extern "C" int casmtr_window_expand_idx(const int64_t* topk_pos, int64_t* up_idx
     if (total <= 0) return 0;
     long long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    ProfScope ps(CASMTR_PROF_WINDOW_WARP, (hipStream_t)stream);
+    ProfScope ps(CASMTR_PROF_WINDOW_WARP, (hipStream_t)stream, "window_expand_idx_kernel");
     hipLaunchKernelGGL(window_expand_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, topk_pos, up_idx, h0,
                        w0, w1, h1 * w1, KW, dilated, total);
     CASMTR_CHECK_LAUNCH();

@@ -394,6 +394,7 @@ static int launch_wm_pair(const WPairArgs& a, hipStream_t s) {
     const long long work = (long long)a.B * a.nitems;
     long long blocks = resident;
     if (blocks > (work + 1) / 2) blocks = ((work + 1) / 2 + 7) / 8 * 8;
+    prof_symbol_args(CASMTR_PROF_WINDOW_MATCH, "<%d,%s>", C, RECIP ? "true" : "false");
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_WINDOW_MATCH, (window_match_pair_kernel<C, RECIP>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     return 0;

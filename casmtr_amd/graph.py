@@ -18,16 +18,20 @@ from typing import Dict, List
 
 import torch
 
-_SNAP_MAX = 1 << 22   # elements: everything finalize() reads is far smaller; conf / similarity matrices are referenced, not copied
+# What finalize() reads of a stage's `_pending` entry (CoarseMatching.finalize / CascadeMatching.finalize): the device-side count and
+# the capacity-sized lists.  These are ALWAYS snapshotted, whatever their size (at the 1/2 level a batch of 25+ pairs at 832x832
+# has lists of more than 4 M entries).  Everything else in the entry (conf / similarity matrices, workspaces, dense per-token
+# outputs) stays a reference to the graph's own buffer: valid until the next replay, never read by finalize().
+_SNAP_KEYS = ("n", "b_ids", "i_ids", "j_ids", "mconf")
 
 
-def _snap_struct(x, make):
+def _snap_struct(x, make, key=None):
     if torch.is_tensor(x):
-        return make(x) if x.numel() <= _SNAP_MAX else x
+        return make(x) if key in _SNAP_KEYS else x
     if isinstance(x, dict):
-        return {k: _snap_struct(v, make) for k, v in x.items()}
+        return {k: _snap_struct(v, make, k) for k, v in x.items()}
     if isinstance(x, (tuple, list)):
-        return type(x)(_snap_struct(v, make) for v in x)
+        return type(x)(_snap_struct(v, make, key) for v in x)
     return x
 
 

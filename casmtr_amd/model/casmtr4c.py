@@ -558,7 +558,8 @@ class CasMTR4c(nn.Module):
         self.backbone = TwinsFPN(b)
         self.pos_encoding_8c = SinePositionEncoding(b[2], (ts // 8, ts // 8))
         self.loftr_coarse_8c = CoarseTransformer(c["coarse"])
-        self.coarse_matching_8c = CoarseMatching(c["match_coarse"], c["coarse"], materialize_conf=False, gemm="split")
+        self.coarse_matching_8c = CoarseMatching(c["match_coarse"], c["coarse"], materialize_conf=False,
+                                                 gemm=c["match_coarse"].get("gemm", "split"))   # config knob; see ops.ds_gemm_mode
         self.pos_encoding_4c = SinePositionEncoding(b[1], (ts // 4, ts // 4))
         self.up_block1 = UpBlock(b[2], b[1])
         self.loftr_coarse_4c = CascadeTransformer(c["coarse2"])

@@ -255,7 +255,8 @@ class CasMTRIndoor4c(nn.Module):
         self.backbone = ResNetFPN(c["resnetfpn"])
         self.pos_encoding = SinePositionEncoding(c["coarse"]["d_model"], (480 // 8, 640 // 8))   # hard-wired to ScanNet frames (:88)
         self.loftr_coarse = CoarseTransformer(c["coarse"])
-        self.coarse_matching = CoarseMatching(c["match_coarse"], c["coarse"], materialize_conf=False, gemm="split")
+        self.coarse_matching = CoarseMatching(c["match_coarse"], c["coarse"], materialize_conf=False,
+                                              gemm=c["match_coarse"].get("gemm", "split"))   # config knob; see ops.ds_gemm_mode
         self.ladder = Ladder(c["resnetfpn"])
         self.pos_encoding_4c = SinePositionEncoding(r[1], (ts // 4, ts // 4))
         self.up_block1 = UpBlock(r[2], r[1])

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 4
+#define CASMTR_ABI_VERSION 5
 int casmtr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -291,7 +291,11 @@ int casmtr_prof_enable_only(int id);
 /* create `pairs` event pairs now, so that no hipEventCreate falls into a timed region (bench.py: launches per step x timed steps) */
 int casmtr_prof_reserve(int pairs);
 int casmtr_prof_read(int id, double* total_ms, int* count);
+/* the individual launch durations (ms) of scope `id`, in launch order: writes min(count, cap) values, returns the count (-1: error) */
+int casmtr_prof_read_all(int id, double* ms_out, int cap);
+/* name of scope `id` (a stage of the path) / the kernel symbol(s) that ran under it since it was last timed ("" if none) */
 const char* casmtr_prof_name(int id);
+const char* casmtr_prof_symbol(int id);
 
 #ifdef __cplusplus
 }

@@ -95,3 +95,77 @@ def test_match_gatherer_needs_pairs_per_step():
         cdist.MatchGatherer(every=4)
     cdist.MatchGatherer(every=1)                       # the per-batch exchange needs none
     cdist.MatchGatherer(every=4, pairs_per_step=8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# bench.py's own N > 1 code path, end to end, under gloo: `python -m torch.distributed.run ... bench.py --gpus 2
+# --total-pairs 5 --mock-hotpath` runs main()'s sharding, parameter broadcast, MatchGatherer and timed loop on two CPU ranks; only the
+# kernels are replaced by deterministic synthetic match lists (bench.mock_lists: empty for some (pair, step), 20 000 entries for pair 3).
+def _expected_exchanges(total, world, steps, warmup, every):
+    """what rank 0 must receive, recomputed independently from bench.mock_lists"""
+    import importlib.util
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_mock", _os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from casmtr_amd import dist as cdist
+    ranges = [cdist.shard_range(total, r, world) for r in range(world)]
+    window = every if every > 0 else 1 << 30
+    out, held = [], []
+
+    def flush():
+        if not held:
+            return
+        counts, sb, sc = [], 0, 0.0
+        for lo, hi in ranges:                      # rank-major, then held step, then pair: gather_matches' concatenation order
+            c = 0
+            for i, step in enumerate(held):
+                for g in range(lo, hi):
+                    n, code = bench.mock_lists(g, step)
+                    c += n
+                    sb += n * (g + (i * total if window > 1 else 0))
+                    sc += n * code
+            counts.append(c)
+        out.append({"n_total": sum(counts), "counts": counts, "sum_m_bids": sb, "sum_code": sc, "mk_shape": [sum(counts), 5]})
+        del held[:]
+
+    for step in range(warmup, warmup + steps):
+        held.append(step)
+        if len(held) >= window:
+            flush()
+    flush()
+    return out
+
+
+def _run_mock_bench(every, total=5, world=2, steps=7, warmup=2):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup",
+           str(warmup), "--total-pairs", str(total), "--gather-every", str(every), "--mock-hotpath"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line, from rank 0"
+    return json.loads(lines[0])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("every", [0, 1, 3])
+def test_bench_main_under_gloo_world2(every):
+    """--gather-every 0 (one final exchange inside the timed region), 1 (per step) and 3 (windows of 3, last one partial)"""
+    steps, warmup, total = 7, 2, 5
+    d = _run_mock_bench(every, total=total, steps=steps, warmup=warmup)
+    assert d["mock"] and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["pairs_this_rank"] == 3 and d["first_timed_step"] == warmup
+    want = _expected_exchanges(total, 2, steps, warmup, every)
+    assert len(d["exchanges"]) == len(want) == {0: 1, 1: 7, 3: 3}[every]
+    for got, w in zip(d["exchanges"], want):
+        assert got["counts"] == w["counts"] and got["n_total"] == w["n_total"] and got["mk_shape"] == w["mk_shape"]
+        assert got["sum_m_bids"] == w["sum_m_bids"], "global pair ids (shard offset + held-step offset)"
+        assert abs(got["sum_code"] - w["sum_code"]) < 1e-3 * max(1.0, abs(w["sum_code"]))
+    assert max(max(g["counts"]) for g in d["exchanges"]) >= 20000, "the large list travelled"

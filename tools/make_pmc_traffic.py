@@ -14,16 +14,16 @@ BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_k
               ("fine_level_dma_kernel<1", "qta_fine_level[lists<=64]"), ("fine_level_dma_kernel<2", "qta_fine_level[lists>64]"),
               ("fine_level_vreg_kernel", "qta_fine_level[lists<=64]"),
               ("quad_attn_kernel<8, 64, 0>", "qta_fine_level[lists<=64]"), ("quad_attn_kernel<8, 128, 0>", "qta_fine_level[lists>64]"),
-              ("nchw_to_quads_kernel", "nchw_to_quads_kernel"),
-              ("quad_attn_kernel<4, 128, 1>", "quad_attn_kernel<cascade>"), ("cascade_attn_dma_kernel", "quad_attn_kernel<cascade>"),
-              ("cascade_quad_kernel", "quad_attn_kernel<cascade>"),
-              ("coarse_fused_kernel", "coarse_fused_kernel"), ("coarse_tile_kernel", "coarse_fused_kernel"), ("window_match", "window_match_kernel"),
-              ("ds_gemm16_kernel", "ds_gemm_kernel"), ("ds_gemm_kernel<", "ds_gemm_kernel[exact fp32; in split mode: the guarded fallback launch]"),
-              ("ds_sparse_kernel", "ds_conf_kernel"), ("ds_conf_kernel", "ds_conf_kernel[dense]"),
-              ("ds_split_kernel", "ds_split_kernel"), ("ds_rownorm_kernel", "ds_split_kernel"), ("ds_fix_kernel", "ds_fix_kernel"),
-              ("nchw_to_tokens_kernel", "nchw_to_tokens_kernel"), ("coarse_row_kernel", "coarse_row_kernel"),
+              ("nchw_to_quads_kernel", "layout"),
+              ("quad_attn_kernel<4, 128, 1>", "cascade_attn"), ("cascade_attn_dma_kernel", "cascade_attn"),
+              ("cascade_quad_kernel", "cascade_attn"),
+              ("coarse_fused_kernel", "qta_coarsest_level"), ("coarse_tile_kernel", "qta_coarsest_level"), ("window_match", "window_match"),
+              ("ds_gemm16_kernel", "dual_softmax_gemm"), ("ds_gemm_kernel<", "dual_softmax_gemm[exact fp32; in split mode: the guarded fallback launch]"),
+              ("ds_sparse_kernel", "dual_softmax_pass2"), ("ds_conf_kernel", "dual_softmax_pass2[dense]"),
+              ("ds_split_kernel", "dual_softmax_split_prepass"), ("ds_rownorm_kernel", "dual_softmax_split_prepass"), ("ds_fix_kernel", "dual_softmax_fix"),
+              ("nchw_to_tokens_kernel", "layout[token-major]"), ("coarse_row_kernel", "coarse_row_kernel"),
               ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel"),
-              ("linear_nt_kernel", "linear_nt_kernel"), ("token_pool_kernel", "token_pool_kernel")]
+              ("linear_nt_kernel", "linear_nt"), ("token_pool_kernel", "token_pool")]
 
 
 def per_kernel(path, counter):
