@@ -8,6 +8,8 @@
 #define DS_BN 128
 #define DS_BK 32
 #define DS_CAND_CAP 8        // near-tie candidates kept per row / column; more -> the whole call falls back to the exact GEMM
+#define DS_X_CAP 8192        // borderline entries (confidence near thr / near a row or column runner-up) re-decided exactly per call
+#define DS_XL_CAP 8192       // rows / columns whose softmax statistics are recomputed with the exact chain for them
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
@@ -21,7 +23,11 @@ struct DsWs {  // carve of stats_ws
     // ---- split path only (everything from rcnt to ovf is zeroed together with rbest / cbest)
     int *rcnt, *ccnt;                // candidates found per row / column
     unsigned *namax, *nbmax;         // [B] max row norm (float bits)
-    int* ovf;                        // != 0: some row / column had more than DS_CAND_CAP candidates
+    int* ovf;                        // != 0: some row / column had more than DS_CAND_CAP candidates (or a borderline list overflowed)
+    // exact re-decision of borderline match-list entries (ds_split.hip, "match list exact by construction")
+    int* xcnt;                       // [4]: entries, needed rows, needed columns, spare
+    unsigned char *rneed, *cneed;    // [B*L], [B*S] line already on rlist / clist
+    unsigned char* rdec;             // [B*L] bit 0: the row's match decision was re-made exactly, bit 1: it is a match
     char* zero_end;
     unsigned char* flags;            // [B*L]
     int64_t* jsel;                   // [B*L]
@@ -33,6 +39,11 @@ struct DsWs {  // carve of stats_ws
     float *rthr, *cthr;              // [B*L], [B*S] candidate thresholds
     float* cg_m;                     // [B][NIB][8][S] column maxima of the 16-row groups (wr, ti, hi) of each 128-row block
     int *rcand, *ccand;              // [B*L][CAP], [B*S][CAP]
+    int* xent;                       // [DS_X_CAP][2] (global row b*L+i, column j)
+    float* xcf;                      // [DS_X_CAP] exact confidence of the entry
+    int *rlist, *clist;              // [DS_XL_CAP] global row ids b*L+i / column ids b*S+j
+    int* rdec_j;                     // [B*L] exactly re-decided rows: the row's best column ...
+    float* rdec_cf;                  // [B*L] ... and its exact confidence
     _Float16 *imgA, *imgB;           // tile images [B][NIB][C/32][4 kg][2 parts][128 rows][8]
 };
 
@@ -56,6 +67,8 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
     if (C > 0) {
         CARVE(rcnt, int, (size_t)B * L); CARVE(ccnt, int, (size_t)B * S);
         CARVE(namax, unsigned, B); CARVE(nbmax, unsigned, B); CARVE(ovf, int, 1);
+        CARVE(xcnt, int, 4); CARVE(rneed, unsigned char, (size_t)B * L); CARVE(cneed, unsigned char, (size_t)B * S);
+        CARVE(rdec, unsigned char, (size_t)B * L);
     }
     if (w) w->zero_end = base + off;
     CARVE(flags, unsigned char, (size_t)B * L); CARVE(jsel, int64_t, (size_t)B * L); CARVE(csel, float, (size_t)B * L);
@@ -67,6 +80,8 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
         CARVE(rthr, float, (size_t)B * L); CARVE(cthr, float, (size_t)B * S);
         CARVE(cg_m, float, (size_t)B * NIB * 8 * S);
         CARVE(rcand, int, (size_t)B * L * DS_CAND_CAP); CARVE(ccand, int, (size_t)B * S * DS_CAND_CAP);
+        CARVE(xent, int, 2 * DS_X_CAP); CARVE(xcf, float, DS_X_CAP); CARVE(rlist, int, DS_XL_CAP); CARVE(clist, int, DS_XL_CAP);
+        CARVE(rdec_j, int, (size_t)B * L); CARVE(rdec_cf, float, (size_t)B * L);
         CARVE(imgA, _Float16, (size_t)B * Lp * C * 2); CARVE(imgB, _Float16, (size_t)B * Sp * C * 2);
     }
 #undef CARVE
@@ -229,8 +244,24 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
 int ds_split_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L, int S,
                     int C, float temperature, int recip, hipStream_t s);
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s);
-int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, hipStream_t s);
+int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, float kthr, hipStream_t s);
 int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
                   int64_t* next_idx01, int64_t* next_idx10, hipStream_t s);
+int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L,
+                      int S, int C, float temperature, int recip, float thr, float* next_conf01, float* next_conf10, hipStream_t s);
+
+// Relative band inside which an approximate (split-path) confidence cannot be ordered against another one, or against thr, with
+// certainty: conf = p01 * p10, each p = exp(x - max) / sum with every logit of the row / column off by at most
+// e = 2^-15 |a||b| / (C T) (the pair's largest norms: namax * nbmax) -> 4 e per factor, 8 e for the product, plus the two paths'
+// different summation orders (~1e-6).  `kthr` = 2^-14 / T (= 2 e per unit norm product).  Entries further apart than 2 * band
+// compare the same way in the exact path.
+__device__ __forceinline__ float ds_conf_band(float kthr, unsigned namax_bits, unsigned nbmax_bits) {
+    return 4.25f * kthr * __uint_as_float(namax_bits) * __uint_as_float(nbmax_bits) + 4e-6f;
+}
+// appends (global row, column) to the borderline list; overflow raises the fallback flag (the exact passes then decide everything)
+__device__ __forceinline__ void ds_x_append(const DsWs& w, int ro, int j) {
+    const int slot = atomicAdd(w.xcnt, 1);
+    if (slot < DS_X_CAP) { w.xent[2 * slot] = ro; w.xent[2 * slot + 1] = j; } else *w.ovf = 1;
+}
 
 }  // namespace casmtr

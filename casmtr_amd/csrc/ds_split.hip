@@ -420,7 +420,7 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
 // segment, which also feeds the column-best atomics.  Same candidate lists and best-of-row / best-of-column keys as the dense pass.
 #define DS_SP_CHUNK 8
 __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict__ sim, DsWs w, int B, int L, int S, int NJB, int NIB,
-                                                        float thr) {
+                                                        float thr, float kthr) {
     const int lane = threadIdx.x & 63;
     const int gw0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int RG = (L + 63) / 64, CG = (S + 63) / 64;
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
         const size_t ro = (size_t)b * L + (ok ? i : L - 1);
         const float rm = w.rmax[ro], rs = w.rsum[ro], rt = w.rthr[ro];
         const float tau = rm + __logf(thr * rs) - 1e-2f, rinv = 1.0f / rs;
+        const float keep = 1.0f - 2.0f * ds_conf_band(kthr, w.namax[b], w.nbmax[b]), cmin = 0.9f * thr;
         const float lim = fminf(rt, tau);
         float mv[DS_SP_CHUNK];
 #pragma unroll
@@ -484,8 +485,23 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
                             const float cf = (__expf(x - w.cmax[co]) * (1.0f / w.csum[co])) * (__expf(x - rm_l) * rinv_l);
                             if (cf >= 0.f) {
                                 const unsigned long long hi = (unsigned long long)__float_as_uint(cf) << 32;
-                                atomicMax(w.rbest + o, hi | (0xFFFFFFFFu - (unsigned)j));
-                                atomicMax(w.cbest + co, hi | (0xFFFFFFFFu - (unsigned)r));
+                                const unsigned long long oldr = atomicMax(w.rbest + o, hi | (0xFFFFFFFFu - (unsigned)j));
+                                const unsigned long long oldc = atomicMax(w.cbest + co, hi | (0xFFFFFFFFu - (unsigned)r));
+                                // Borderline entries (see ds_xdecide_launch): the previous maximum `old` and this entry are within the
+                                // error band of each other -> neither ordering is certain -> both go on the list for exact
+                                // re-decision.  Every entry within the band of the FINAL maximum is caught this way: it either
+                                // meets the final maximum as `old`, or is met as `old` by the chain of later maxima that ends there.
+                                if (cf > cmin) {
+                                    const float cr = __uint_as_float((unsigned)(oldr >> 32)), cc = __uint_as_float((unsigned)(oldc >> 32));
+                                    if (fminf(cf, cr) > cmin && fminf(cf, cr) >= fmaxf(cf, cr) * keep) {
+                                        ds_x_append(w, (int)o, j);
+                                        ds_x_append(w, (int)o, (int)(0xFFFFFFFFu - (unsigned)(oldr & 0xFFFFFFFFu)));
+                                    }
+                                    if (fminf(cf, cc) > cmin && fminf(cf, cc) >= fmaxf(cf, cc) * keep) {
+                                        ds_x_append(w, (int)o, j);
+                                        ds_x_append(w, b * L + (int)(0xFFFFFFFFu - (unsigned)(oldc & 0xFFFFFFFFu)), j);
+                                    }
+                                }
                             }
                         }
                     }
@@ -549,10 +565,10 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
     }
 }
 
-int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, hipStream_t s) {
+int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, float kthr, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const int waves = B * ((L + 63) / 64) * ((NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK) + B * ((S + 63) / 64) * ((NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK);
-    hipLaunchKernelGGL(ds_sparse_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, sim, w, B, L, S, NJB, NIB, thr);
+    hipLaunchKernelGGL(ds_sparse_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, sim, w, B, L, S, NJB, NIB, thr, kthr);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
@@ -608,6 +624,241 @@ int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, 
     else
         hipLaunchKernelGGL(ds_fix_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, s, feat0, feat1, w, B, L, S, C, sqrtC,
                            1.0f / sqrtC, temperature, 1.0f / temperature, next_idx01, next_idx10);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================== exact match list
+// "Match list exact by construction" (VERDICT r04 item 3).  coarse_matching.py:116-132 decides a match from three float comparisons
+// on conf = softmax_row * softmax_col: conf > thr, conf == its row's maximum, conf == its column's maximum.  The split path's
+// confidences carry a relative error of up to `band` (ds_conf_band), so any of those comparisons can come out differently from the
+// exact path's when the two sides are closer than that.  Pass 2 and ds_xnear_kernel put every entry for which that can happen on a
+// list (typically a few dozen per batch: confidences within 0.5 % of thr or of a runner-up); for those entries
+//   * the logit is recomputed with the oracle's fmaf chain (as ds_fix_kernel does for the argmax candidates),
+//   * the softmax statistics of their row AND their column are recomputed from exact logits, in exactly the order the exact
+//     kernels use (ds_tile_epilogue<RECIP, false>: 32-entry lane runs, lane pairs, wave pairs; ds_reduce_kernel: 128-wide blocks
+//     ascending), so that max, sum and hence conf are BIT-IDENTICAL to casmtr_dual_softmax_fwd's,
+//   * and the rows concerned take their decision (best column, conf > thr, mutual maximum) from those values.
+// Entries not on the list are further than 2 * band from every decision boundary they take part in: the approximate comparison and
+// the exact one agree.  Net effect: the (b, i, j) list equals the exact path's on every input; mconf of a re-decided row is the exact
+// value, the other mconf values stay within the split's 1e-6.  Lists that overflow raise w.ovf -> the exact passes decide.
+
+// (1) thread per row: the row's approximate best sits within the band of thr -> borderline
+__global__ __launch_bounds__(256) void ds_xnear_kernel(DsWs w, int L, int total, float thr, float kthr) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned long long key = w.rbest[t];
+    if (!key) return;
+    const float cf = __uint_as_float((unsigned)(key >> 32));
+    const int b = t / L;
+    const float band = ds_conf_band(kthr, w.namax[b], w.nbmax[b]);
+    if (fabsf(cf - thr) <= band * fmaxf(cf, thr)) ds_x_append(w, t, (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)));
+}
+
+// (2) thread per listed entry: its row and its column need exact statistics (each line is claimed once)
+__global__ __launch_bounds__(256) void ds_xclaim_kernel(DsWs w, int L, int S) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(w.xcnt[0], DS_X_CAP);
+    if (t >= n) return;
+    const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
+    const int co = (ro / L) * S + j;
+    // byte flags inside 4-byte words: claim with an atomic OR on the containing word
+    auto claim = [](unsigned char* flags, int idx) {
+        unsigned* wp = reinterpret_cast<unsigned*>(flags) + (idx >> 2);
+        const unsigned bit = 1u << ((idx & 3) * 8);
+        return (atomicOr(wp, bit) & bit) == 0;
+    };
+    if (claim(w.rneed, ro)) {
+        const int slot = atomicAdd(w.xcnt + 1, 1);
+        if (slot < DS_XL_CAP) w.rlist[slot] = ro; else *w.ovf = 1;
+    }
+    if (claim(w.cneed, co)) {
+        const int slot = atomicAdd(w.xcnt + 2, 1);
+        if (slot < DS_XL_CAP) w.clist[slot] = co; else *w.ovf = 1;
+    }
+}
+
+// the oracle's logit of (row i of feat0, row j of feat1): fmaf chain over c ascending of the 1/sqrt(C)-scaled operands, then / T
+template <bool RECIP>
+__device__ __forceinline__ float ds_exact_logit(const float* __restrict__ pa, const float* __restrict__ pb, int C, float sqrtC,
+                                                float inv_sqrtC, float T, float invT) {
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 4) {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(pa + c), vb = *reinterpret_cast<const f32x4*>(pb + c);
+        acc = __builtin_fmaf(div_scalar<RECIP>(va.x, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.x, sqrtC, inv_sqrtC), acc);
+        acc = __builtin_fmaf(div_scalar<RECIP>(va.y, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.y, sqrtC, inv_sqrtC), acc);
+        acc = __builtin_fmaf(div_scalar<RECIP>(va.z, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.z, sqrtC, inv_sqrtC), acc);
+        acc = __builtin_fmaf(div_scalar<RECIP>(va.w, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.w, sqrtC, inv_sqrtC), acc);
+    }
+    return div_scalar<RECIP>(acc, T, invT);
+}
+
+// (3) exact (max, sum exp) partial of one listed line over one 128-wide block, in ds_tile_epilogue<RECIP, false>'s order.
+// Four lanes per (line, block): lane q = 2 * half + hi owns the 32 entries that one LANE of the tile kernel reduces --
+//   rows:    wave wc = half of the tile covers columns 64 wc .. 64 wc + 63; its lane (hi, row) scans columns 32 hi + c, c ascending;
+//   columns: wave wr = half covers rows 64 wr .. 64 wr + 63; its lane (hi, col) scans rows 32 ti + (r & 3) + 8 (r >> 2) + 4 hi in
+//            (ti, r) order --
+// then the lane pair (hi = 0, 1) shares its maximum and adds its sums, and the two halves combine as the tile kernel's step 4 does.
+template <bool RECIP>
+__global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                        const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
+                                                        int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT, int NJB,
+                                                        int NIB) {
+    const int nr = min(w.xcnt[1], DS_XL_CAP), nc = min(w.xcnt[2], DS_XL_CAP);
+    const long long units = ((long long)nr * NJB + (long long)nc * NIB) * 4;
+    for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < ((units + 63) & ~63ll); u += (long long)gridDim.x * blockDim.x) {
+        const bool live = u < units;                       // whole waves stay in the loop: the shuffles below need their partners
+        const long long g = (live ? u : units - 1) >> 2;
+        const int q = (int)(u & 3), half = q >> 1, hi = q & 1;
+        const bool col = g >= (long long)nr * NJB;
+        const long long gg = col ? g - (long long)nr * NJB : g;
+        const int nblk = col ? NIB : NJB;
+        const int line = (col ? w.clist : w.rlist)[gg / nblk], t = (int)(gg % nblk);
+        const int N = col ? S : L, M = col ? L : S;        // own side / other side
+        const int b = line / N, self = line % N;
+        const float* pself = (col ? f1 : f0) + ((size_t)b * N + self) * C;
+        const float* pother = (col ? f0 : f1) + (size_t)b * M * C;
+        const bool self_masked = mask0 && (col ? mask1 : mask0)[(size_t)b * N + self] == 0;
+        const uint8_t* mother = mask0 ? (col ? mask0 : mask1) + (size_t)b * M : nullptr;
+        float x[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            // e-th entry of this lane's run: rows -> column 32 hi + e of the half; columns -> row 32 ti + (r & 3) + 8 (r >> 2) + 4 hi
+            const int local = col ? ((e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hi) : (32 * hi + e);
+            const int o = t * 128 + half * 64 + local;
+            float v = -INFINITY;                            // outside the matrix: never wins a max, adds exp(-inf) = 0
+            if (o < M) {
+                if (self_masked || (mother && mother[o] == 0)) v = NEG_FILL;
+                else v = col ? ds_exact_logit<RECIP>(pother + (size_t)o * C, pself, C, sqrtC, inv_sqrtC, T, invT)
+                             : ds_exact_logit<RECIP>(pself, pother + (size_t)o * C, C, sqrtC, inv_sqrtC, T, invT);
+            }
+            x[e] = v;
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) m = x[e] > m ? x[e] : m;
+        const float pm = __shfl_xor(m, 1);
+        m = pm > m ? pm : m;
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) sm += __expf(x[e] - m);
+        sm += __shfl_xor(sm, 1);
+        // step 4 of the tile epilogue: halves 0 and 1
+        const float mo = __shfl_xor(m, 2), so = __shfl_xor(sm, 2);
+        const float ma = half ? mo : m, mb = half ? m : mo, sa = half ? so : sm, sb = half ? sm : so;
+        const float mm = mb > ma ? mb : ma;
+        float tot = 0.f;
+        if (ma > -INFINITY) tot += sa * __expf(ma - mm);
+        if (mb > -INFINITY) tot += sb * __expf(mb - mm);
+        if (live && q == 0) {
+            const size_t o = ((size_t)b * nblk + t) * N + self;
+            (col ? w.cp_m : w.rp_m)[o] = mm;
+            (col ? w.cp_s : w.rp_s)[o] = tot;
+        }
+    }
+}
+
+// (4) thread per listed line: block partials -> (max, sum) exactly as ds_reduce_kernel; next_conf = 1 / sum follows
+__global__ __launch_bounds__(256) void ds_xreduce_kernel(DsWs w, int L, int S, int NJB, int NIB, float* __restrict__ next_conf01,
+                                                         float* __restrict__ next_conf10) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nr = min(w.xcnt[1], DS_XL_CAP), nc = min(w.xcnt[2], DS_XL_CAP);
+    if (t >= nr + nc) return;
+    const bool col = t >= nr;
+    const int line = col ? w.clist[t - nr] : w.rlist[t];
+    const int N = col ? S : L, nblk = col ? NIB : NJB;
+    const int b = line / N, self = line % N;
+    const float* pm = (col ? w.cp_m : w.rp_m) + (size_t)b * nblk * N + self;
+    const float* ps = (col ? w.cp_s : w.rp_s) + (size_t)b * nblk * N + self;
+    float m = pm[0];
+    for (int k = 1; k < nblk; ++k) {
+        const float x = pm[(size_t)k * N];
+        if (x > m) m = x;
+    }
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += ps[(size_t)k * N] * __expf(pm[(size_t)k * N] - m);
+    (col ? w.cmax : w.rmax)[line] = m;
+    (col ? w.csum : w.rsum)[line] = s;
+    (col ? next_conf10 : next_conf01)[line] = 1.0f / s;
+}
+
+// (5) thread per listed entry: exact confidence, the expression of ds_conf_kernel<false>
+template <bool RECIP>
+__global__ __launch_bounds__(256) void ds_xconf_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                       const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
+                                                       int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= min(w.xcnt[0], DS_X_CAP)) return;
+    const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
+    const int b = ro / L, i = ro % L;
+    const size_t co = (size_t)b * S + j;
+    float x = NEG_FILL;
+    if (!(mask0 && (mask0[ro] == 0 || mask1[co] == 0)))
+        x = ds_exact_logit<RECIP>(f0 + (size_t)ro * C, f1 + co * C, C, sqrtC, inv_sqrtC, T, invT);
+    const float rm = w.rmax[ro], rinv = 1.0f / w.rsum[ro], cm = w.cmax[co], cinv = 1.0f / w.csum[co];
+    const float p01 = __expf(x - rm) * rinv;
+    const float p10 = __expf(x - cm) * cinv;
+    w.xcf[t] = p10 * p01;
+    (void)i;
+}
+
+// (6) thread per listed entry e = (i, j): is e the exact best of row i (first column among equal values) and does it satisfy
+// conf > thr and conf == column maximum?  Entries of row i / column j that are NOT listed lie below the band of the line's
+// approximate best; so if that best itself is not listed, nothing listed can be the line's maximum.
+__global__ __launch_bounds__(256) void ds_xdecide_kernel(DsWs w, int L, int S, float thr) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(w.xcnt[0], DS_X_CAP);
+    if (t >= n) return;
+    const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
+    const int b = ro / L;
+    const size_t co = (size_t)b * S + j;
+    const float cf = w.xcf[t];
+    const int jbest = (int)(0xFFFFFFFFu - (unsigned)(w.rbest[ro] & 0xFFFFFFFFu));
+    const int ibest = (int)(0xFFFFFFFFu - (unsigned)(w.cbest[co] & 0xFFFFFFFFu));
+    bool row_listed = false, col_listed = false;   // the row's / the column's approximate best is on the list
+    bool row_win = true, col_win = true;
+    for (int k = 0; k < n; ++k) {
+        const int ro2 = w.xent[2 * k], j2 = w.xent[2 * k + 1];
+        const float c2 = w.xcf[k];
+        if (ro2 == ro) {
+            row_listed |= j2 == jbest;
+            if (c2 > cf || (c2 == cf && j2 < j)) row_win = false;   // rbest semantics: maximal value, first column
+        }
+        if (j2 == j && ro2 / L == b) {
+            col_listed |= (ro2 % L) == ibest;
+            if (c2 > cf) col_win = false;                             // mutual maximum BY VALUE (coarse_matching.py:120-122)
+        }
+    }
+    if (!row_listed || !row_win) return;      // not this row's exact best (or the row is decided by an unlisted, clearly larger entry)
+    const bool ok = cf > thr && col_listed && col_win;
+    w.rdec_j[ro] = j;                          // duplicates of e write the same values
+    w.rdec_cf[ro] = cf;
+    w.rdec[ro] = ok ? 3 : 1;
+}
+
+int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L,
+                      int S, int C, float temperature, int recip, float thr, float* next_conf01, float* next_conf10, hipStream_t s) {
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    const float sqrtC = (float)sqrt((double)C), kthr = 6.103515625e-05f / temperature;
+    hipLaunchKernelGGL(ds_xnear_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, L, B * L, thr, kthr);
+    hipLaunchKernelGGL(ds_xclaim_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, L, S);
+    CASMTR_CHECK_LAUNCH();
+    // listed lines x blocks x 4 lanes, grid-strided; a typical batch lists a few dozen lines (~30 k threads)
+    if (recip)
+        hipLaunchKernelGGL(ds_xstats_kernel<true>, dim3(1024), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC, 1.0f / sqrtC,
+                           temperature, 1.0f / temperature, NJB, NIB);
+    else
+        hipLaunchKernelGGL(ds_xstats_kernel<false>, dim3(1024), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC, 1.0f / sqrtC,
+                           temperature, 1.0f / temperature, NJB, NIB);
+    hipLaunchKernelGGL(ds_xreduce_kernel, dim3(2 * DS_XL_CAP / 256), dim3(256), 0, s, w, L, S, NJB, NIB, next_conf01, next_conf10);
+    CASMTR_CHECK_LAUNCH();
+    if (recip)
+        hipLaunchKernelGGL(ds_xconf_kernel<true>, dim3(DS_X_CAP / 256), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC,
+                           1.0f / sqrtC, temperature, 1.0f / temperature);
+    else
+        hipLaunchKernelGGL(ds_xconf_kernel<false>, dim3(DS_X_CAP / 256), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC,
+                           1.0f / sqrtC, temperature, 1.0f / temperature);
+    hipLaunchKernelGGL(ds_xdecide_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, L, S, thr);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict_
 // candidate list (almost always exactly one: the maximum itself).  Masked entries never are.
 template <bool CAND>
 __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, DsWs w, int L, int S, int want_conf, float thr,
-                                                      const int* __restrict__ guard) {
+                                                      const int* __restrict__ guard, float kthr) {
     if (guard && *guard == 0) return;
     const int b = blockIdx.z, i0 = blockIdx.y * DSC_ROWS;
     const int lane = threadIdx.x & 63;
@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
     const float* rmax = w.rmax + (size_t)b * L + i0;   // wave-uniform
     const float* rsum = w.rsum + (size_t)b * L + i0;
     const float* rthr = CAND ? w.rthr + (size_t)b * L + i0 : nullptr;
+    // CAND: borderline entries for the exact re-decision of the match list (ds_split.hip: ds_xdecide_launch; same rule as ds_sparse_kernel)
+    const float keep = CAND ? 1.0f - 2.0f * ds_conf_band(kthr, w.namax[b], w.nbmax[b]) : 0.f, cmin = 0.9f * thr;
     float* base = sim + ((size_t)b * L + i0) * S + j;
     constexpr int RU = 4;  // rows in flight per lane
     for (int r0 = 0; r0 < nr; r0 += RU) {
@@ -230,6 +232,10 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
                 const float p01 = __expf(x[q][u] - rm) * rinv;
                 const float p10 = __expf(x[q][u] - cm[u]) * cinv[u];
                 cf[u] = (j + u < S) ? p10 * p01 : -1.f;
+                if (CAND && fminf(cf[u], best[u]) > cmin && fminf(cf[u], best[u]) >= fmaxf(cf[u], best[u]) * keep) {
+                    ds_x_append(w, b * L + i0 + r, j + u);     // this entry and the column's best so far cannot be ordered for certain
+                    ds_x_append(w, b * L + bi[u], j + u);
+                }
                 if (cf[u] > best[u]) { best[u] = cf[u]; bi[u] = i0 + r; }
                 if (cf[u] > rbest) { rbest = cf[u]; rj = j + u; }
             }
@@ -244,9 +250,30 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
             const unsigned kb = rbest >= 0.f ? __float_as_uint(rbest) : 0u;
             const unsigned wm = wave_max_u32(kb);
             const unsigned long long bal = __ballot(kb == wm && rbest >= 0.f);
+            if (CAND) {   // more than one entry of this (row, wave) within the band of the wave's best: all of them are borderline
+                const float wmf = __uint_as_float(wm);
+                bool nb[4];
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    nb[u] = cf[u] > cmin && cf[u] >= wmf * keep;
+                    cnt += __popcll(__ballot(nb[u]));
+                }
+                if (cnt > 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (nb[u]) ds_x_append(w, b * L + i0 + r, j + u);
+                }
+            }
             if (bal && lane == __ffsll((long long)bal) - 1) {
                 const unsigned long long key = ((unsigned long long)wm << 32) | (0xFFFFFFFFu - (unsigned)rj);
-                atomicMax(w.rbest + (size_t)b * L + i0 + r, key);
+                const unsigned long long old = atomicMax(w.rbest + (size_t)b * L + i0 + r, key);
+                if (CAND) {
+                    const float cw = __uint_as_float(wm), co = __uint_as_float((unsigned)(old >> 32));
+                    if (fminf(cw, co) > cmin && fminf(cw, co) >= fmaxf(cw, co) * keep) {
+                        ds_x_append(w, b * L + i0 + r, rj);
+                        ds_x_append(w, b * L + i0 + r, (int)(0xFFFFFFFFu - (unsigned)(old & 0xFFFFFFFFu)));
+                    }
+                }
             }
         }
     }
@@ -254,7 +281,14 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
     for (int u = 0; u < 4; ++u)
         if (j + u < S && best[u] >= 0.f) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(best[u]) << 32) | (0xFFFFFFFFu - (unsigned)bi[u]);
-            atomicMax(w.cbest + (size_t)b * S + j + u, key);
+            const unsigned long long old = atomicMax(w.cbest + (size_t)b * S + j + u, key);
+            if (CAND) {
+                const float co = __uint_as_float((unsigned)(old >> 32));
+                if (fminf(best[u], co) > cmin && fminf(best[u], co) >= fmaxf(best[u], co) * keep) {
+                    ds_x_append(w, b * L + bi[u], j + u);
+                    ds_x_append(w, b * L + (int)(0xFFFFFFFFu - (unsigned)(old & 0xFFFFFFFFu)), j + u);
+                }
+            }
         }
 }
 
@@ -265,10 +299,15 @@ __global__ __launch_bounds__(256) void ds_flag_kernel(DsWs w, float thr, int bor
     if (t >= total) return;
     const int b = t / L, i = t % L;
     const unsigned long long key = w.rbest[t];
-    const float cf = __uint_as_float((unsigned)(key >> 32));
-    const int j = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+    float cf = __uint_as_float((unsigned)(key >> 32));
+    int j = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
     bool ok = cf > thr;
     if (ok) ok = (unsigned)(w.cbest[(size_t)b * S + j] >> 32) == (unsigned)(key >> 32);
+    if (w.rdec && (w.rdec[t] & 1)) {   // split path: this row's (best column, conf > thr, mutual maximum) was re-decided exactly
+        ok = (w.rdec[t] & 2) != 0;
+        j = w.rdec_j[t];
+        cf = w.rdec_cf[t];
+    }
     if (ok && border_rm > 0) {
         const int vh0 = valid_hw ? valid_hw[b * 4 + 0] : h0c, vw0 = valid_hw ? valid_hw[b * 4 + 1] : w0c;
         const int vh1 = valid_hw ? valid_hw[b * 4 + 2] : h1c, vw1 = valid_hw ? valid_hw[b * 4 + 3] : w1c;
@@ -419,7 +458,7 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
     {
         ProfScope ps(guard ? -1 : CASMTR_PROF_DS_CONF, s, "ds_conf_kernel<false>");
         hipLaunchKernelGGL(ds_conf_kernel<false>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
-                           w, L, S, want_conf, thr, guard);
+                           w, L, S, want_conf, thr, guard, 0.f);
     }
     CASMTR_CHECK_LAUNCH();
     return 0;
@@ -444,7 +483,7 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     if (C % DS_BK != 0 || (mask0 == nullptr) != (mask1 == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    DsWs w;
+    DsWs w{};
     ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S, 0);
     // a kernel, not hipMemsetAsync: inside a captured HIP graph (casmtr_amd/graph.py) a memset node is not reliably ordered against
     // the kernels around it on this ROCm stack (replays faulted after tens of steps: counters read before they were cleared)
@@ -473,7 +512,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     if (C % DS_BK != 0 || (mask0 == nullptr) != (mask1 == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || L <= 0 || S <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    DsWs w;
+    DsWs w{};
     ds_carve(&w, reinterpret_cast<char*>(stats_ws), B, L, S, C);
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     // a kernel, not hipMemsetAsync: inside a captured HIP graph (casmtr_amd/graph.py) a memset node is not reliably ordered against
@@ -491,9 +530,9 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
         rc = ds_gemm16_launch(mask0, mask1, sim_ws, w, B, L, S, C, s);   // timed inside (events attached to the dispatch)
     }
     if (rc) return rc;
+    const float kthr = 6.103515625e-05f / temperature;   // 2 e = 2^-14 |a_i|/sqrtC max|b_j|/sqrtC / T
     {
         ProfScope ps(CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel x2");
-        const float kthr = 6.103515625e-05f / temperature;   // 2 e = 2^-14 |a_i|/sqrtC max|b_j|/sqrtC / T
         hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, nullptr, NJB, L, B * L,
                            w.rmax, w.rsum, next_idx01, next_conf01, w.na, NIB * DS_BM, w.nbmax, kthr, w.rthr, nullptr);
         CASMTR_CHECK_LAUNCH();
@@ -504,17 +543,25 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     {
         ProfScope ps(CASMTR_PROF_DS_CONF, s, (!want_conf && thr >= 1e-3f) ? "ds_sparse_kernel (segment-sparse pass 2)" : "ds_conf_kernel<true>");
         if (!want_conf && thr >= 1e-3f) {   // segment-sparse pass 2 (the dense one is needed only to write conf_matrix)
-            rc = ds_sparse_launch(sim_ws, w, B, L, S, thr, s);
+            rc = ds_sparse_launch(sim_ws, w, B, L, S, thr, kthr, s);
             if (rc) return rc;
         } else
             hipLaunchKernelGGL(ds_conf_kernel<true>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
-                               w, L, S, want_conf, thr, nullptr);
+                               w, L, S, want_conf, thr, nullptr, kthr);
     }
     CASMTR_CHECK_LAUNCH();
     {
         ProfScope ps(CASMTR_PROF_DS_FIX, s, "ds_fix_kernel + guarded exact-pass launches (exit at once unless a candidate list overflowed)");
         rc = ds_fix_launch(feat0, feat1, w, B, L, S, C, temperature, recip, next_idx01, next_idx10, s);
         if (rc) return rc;
+        // match list exact by construction: every entry whose approximate confidence cannot be ordered for certain against thr, its
+        // row's or its column's runner-up gets its logit, its row's and its column's softmax statistics from the exact chain, in
+        // the exact kernels' own summation order, and the rows concerned are decided from those values (ds_split.hip)
+        rc = ds_xdecide_launch(feat0, feat1, mask0, mask1, w, B, L, S, C, temperature, recip, thr, next_conf01, next_conf10, s);
+        if (rc) return rc;
+        // a list overflowed: the exact passes below decide everything; the re-decisions made from the (truncated) lists are dropped
+        hipLaunchKernelGGL(ds_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(w.rdec),
+                           ((size_t)B * L + 7) / 8, (const int*)w.ovf);
         rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
                              next_idx10, next_conf10, B, L, S, C, w.ovf, s);
     }

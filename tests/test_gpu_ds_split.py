@@ -144,3 +144,84 @@ def test_split_low_threshold_uses_dense_pass(ops):
         assert n == int(ex["n"].item()) and n > 100
         assert torch.equal(sp["i_ids"][:n], ex["i_ids"][:n]) and torch.equal(sp["j_ids"][:n], ex["j_ids"][:n])
         assert torch.equal(sp["next_idx_c01"], ex["next_idx_c01"]) and torch.equal(sp["next_idx_c10"], ex["next_idx_c10"])
+
+
+def _lists(d):
+    n = int(d["n"].item())
+    return n, d["b_ids"][:n], d["i_ids"][:n], d["j_ids"][:n], d["mconf"][:n]
+
+
+def _assert_same_lists(sp, ex, what):
+    ns, bs, is_, js, cs = _lists(sp)
+    ne, be, ie, je, ce = _lists(ex)
+    assert ns == ne, f"{what}: {ns} matches on the split path, {ne} on the exact path"
+    assert torch.equal(bs, be) and torch.equal(is_, ie) and torch.equal(js, je), f"{what}: match lists differ"
+    return cs, ce
+
+
+@pytest.mark.parametrize("want_conf", [False, True])   # sparse pass 2 | dense pass 2 (conf_matrix written)
+def test_split_match_list_exact_by_construction(ops, want_conf):
+    """VERDICT r04 item 3.  The split path's (b, i, j) list must EQUAL the exact path's on every input, not merely in practice.
+    Decision boundaries are planted exactly where the approximate confidences cannot be trusted:
+      * thr set to the exact confidence of a match, and to its float neighbours -- `conf > thr` flips between neighbouring thresholds,
+        the split path's conf of that entry is off by ~1e-6 relative, i.e. thousands of ulps;
+      * bit-identical and one-ulp-apart columns / rows -- row and column maxima tie exactly or within an ulp, so the first-index rule
+        and the mutual-maximum-by-value test are decided on the last bit.
+    Entries near a boundary are re-decided from exact logits and exact statistics (ds_split.hip: ds_xdecide_launch); their mconf must
+    then be the exact path's value bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, h, w, C = 2, 24, 28, 256
+    L = h * w
+    f0 = torch.randn((B, L, C), generator=g)
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(B)])
+    f1 = torch.stack([f0[b][perm[b]] for b in range(B)]) + 0.45 * torch.randn((B, L, C), generator=g)
+    # near-duplicate columns / rows: exact ties and one-ulp differences between competing maxima
+    for b in range(B):
+        for k in range(12):
+            src, dst = int(torch.randint(0, L, (1,), generator=g)), int(torch.randint(0, L, (1,), generator=g))
+            f1[b, dst] = f1[b, src]
+            if k % 3:
+                c = int(torch.randint(0, C, (1,), generator=g))
+                f1[b, dst, c] = torch.nextafter(f1[b, dst, c], torch.tensor(float("inf") if k % 3 == 1 else -float("inf")))
+            src, dst = int(torch.randint(0, L, (1,), generator=g)), int(torch.randint(0, L, (1,), generator=g))
+            f0[b, dst] = f0[b, src]
+    f0, f1 = f0.to(DEV).contiguous(), f1.to(DEV).contiguous()
+    run = lambda gemm, thr: ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=want_conf, gemm=gemm)
+    ex = run("exact", 0.2)
+    n, _, _, _, mc = _lists(ex)
+    assert n > 200
+    _assert_same_lists(run("split", 0.2), ex, "thr = 0.2")
+    # thresholds ON exact confidences: the five smallest confidences above 0.2, a median one and the largest one
+    srt = torch.sort(mc).values
+    picks = [float(srt[k]) for k in (0, 1, 2, 3, 4, n // 2, n - 1)]
+    checked = 0
+    for c in picks:
+        for thr in (float(np.nextafter(np.float32(c), np.float32(0))), c, float(np.nextafter(np.float32(c), np.float32(1)))):
+            e2, s2 = run("exact", thr), run("split", thr)
+            cs, ce = _assert_same_lists(s2, e2, f"thr = {thr!r} (at an exact confidence {c!r})")
+            # entries within the band of thr were re-decided: their mconf is the exact value bit for bit
+            near = (ce - thr).abs() <= 1e-5 * thr
+            assert torch.equal(cs[near], ce[near]), "re-decided entries carry the exact confidence"
+            assert float((cs - ce).abs().max()) < 1e-5 if cs.numel() else True
+            checked += int(near.sum())
+    assert checked >= len(picks), "the planted thresholds actually had entries sitting on them"
+    # indices stay the oracle's as before
+    o = oracle.dual_softmax(f0.cpu().numpy(), f1.cpu().numpy(), (h, w), (h, w), 0.1, 0.2, recip=True)
+    sp = run("split", 0.2)
+    assert np.array_equal(N(sp["next_idx_c01"]), o["next_idx_c01"]) and np.array_equal(N(sp["next_idx_c10"]), o["next_idx_c10"])
+
+
+def test_split_borderline_overflow_falls_back_to_exact(ops):
+    """hundreds of rows with the same top confidence pattern (every row duplicated many times): more borderline entries than the
+    list holds -> the device-side flag sends the call through the exact passes, lists still equal the exact path's"""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    h, w, C = 20, 20, 64
+    L = h * w
+    base = torch.randn((1, 40, C), generator=g)
+    f0 = base[:, torch.arange(L) % 40].contiguous()                    # 10 copies of each of 40 rows
+    f1 = (base[:, torch.arange(L) % 40] * 1.0).contiguous()
+    f0, f1 = f0.to(DEV), f1.to(DEV)
+    for thr in (0.0005, 0.002):
+        ex = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=False, gemm="exact")
+        sp = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=False, gemm="split")
+        _assert_same_lists(sp, ex, f"duplicated rows, thr = {thr}")

@@ -273,6 +273,12 @@ def test_dual_softmax(ops, name, recip, gemm):
     if got == want:
         assert np.array_equal(N(d["i_ids"][:n]), o["i_ids"]) and np.array_equal(N(d["j_ids"][:n]), o["j_ids"]), "order"
         assert_close(N(d["mconf"][:n]), o["mconf"], SOFTMAX_TOL, "mconf")
+    if gemm == "split":   # exact by construction: the SAME list as the all-fp32 path (the <= 1 above is device exp against libm's)
+        ex = ops.dual_softmax(T(inp["feat0"]), T(inp["feat1"]), cfg["hw0"], cfg["hw1"], mask0=None if m0 is None else T(m0),
+                              mask1=None if m1 is None else T(m1), valid_hw=None if valid is None else T(valid), recip=recip,
+                              want_conf=True, gemm="exact", **kw)
+        assert int(ex["n"].item()) == n and torch.equal(ex["i_ids"][:n], d["i_ids"][:n]) and torch.equal(ex["j_ids"][:n], d["j_ids"][:n]) \
+            and torch.equal(ex["b_ids"][:n], d["b_ids"][:n]), "split and exact GEMM paths must return the same match list"
     if not recip:  # the fixtures come from the reference on CPU (true division)
         g = load_golden("coarse_matching", name)
         audit_index_mismatches(N(d["next_idx_c01"]), g["next_idx_c01"], dot_score_fn(inp["feat0"], inp["feat1"], m0, m1), "next_idx_c01 vs reference")
