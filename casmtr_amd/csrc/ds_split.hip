@@ -17,6 +17,8 @@
 // random features.  Sums, probabilities and confidences use the approximate logits (relative error of exp < 1e-4 x |a||b|/(C T) x 0.3).
 #include <stdlib.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "ds_common.hpp"
 #include "../../include/casmtr_hip.h"
 
@@ -643,6 +645,12 @@ int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, 
 // the exact one agree.  Net effect: the (b, i, j) list equals the exact path's on every input; mconf of a re-decided row is the exact
 // value, the other mconf values stay within the split's 1e-6.  Lists that overflow raise w.ovf -> the exact passes decide.
 
+__device__ __forceinline__ void wave_lds_fence_() {   // this wave's LDS writes are visible to its own later reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // (1) thread per row: the row's approximate best sits within the band of thr -> borderline
 __global__ __launch_bounds__(256) void ds_xnear_kernel(DsWs w, int L, int total, float thr, float kthr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,45 +702,78 @@ __device__ __forceinline__ float ds_exact_logit(const float* __restrict__ pa, co
 }
 
 // (3) exact (max, sum exp) partial of one listed line over one 128-wide block, in ds_tile_epilogue<RECIP, false>'s order.
-// Four lanes per (line, block): lane q = 2 * half + hi owns the 32 entries that one LANE of the tile kernel reduces --
+// One wave per (line, block).  The 128 exact logits: lane <-> entry (two halves of 64), the other side's rows through the wave's
+// transposition slab 32 channels at a time (coalesced 128-byte rows; a lane-per-row walk of 10 816 x 1 KB rows per line was
+// texture-address bound: 1.4 ms per step), the chain extended c-ascending across the chunks = the oracle's chain.  Then lanes
+// q = 2 * half + hi < 4 replay what one LANE of the tile kernel reduces, from the logits parked in LDS --
 //   rows:    wave wc = half of the tile covers columns 64 wc .. 64 wc + 63; its lane (hi, row) scans columns 32 hi + c, c ascending;
 //   columns: wave wr = half covers rows 64 wr .. 64 wr + 63; its lane (hi, col) scans rows 32 ti + (r & 3) + 8 (r >> 2) + 4 hi in
 //            (ti, r) order --
-// then the lane pair (hi = 0, 1) shares its maximum and adds its sums, and the two halves combine as the tile kernel's step 4 does.
+// the lane pair (hi = 0, 1) shares its maximum and adds its sums, and the two halves combine as the tile kernel's step 4 does.
 template <bool RECIP>
 __global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                         const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
                                                         int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT, int NJB,
                                                         int NIB) {
+    __shared__ float slabs[4 * (CASMTR_SLAB_FLOATS + 128 + 256)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* slab = slabs + wave * (CASMTR_SLAB_FLOATS + 128 + 256);
+    float* xl = slab + CASMTR_SLAB_FLOATS;                 // the block's 128 logits
+    float* sl = xl + 128;                                  // the line's own feature row, scaled by 1 / sqrt(C) (C <= 256)
     const int nr = min(w.xcnt[1], DS_XL_CAP), nc = min(w.xcnt[2], DS_XL_CAP);
-    const long long units = ((long long)nr * NJB + (long long)nc * NIB) * 4;
-    for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < ((units + 63) & ~63ll); u += (long long)gridDim.x * blockDim.x) {
-        const bool live = u < units;                       // whole waves stay in the loop: the shuffles below need their partners
-        const long long g = (live ? u : units - 1) >> 2;
-        const int q = (int)(u & 3), half = q >> 1, hi = q & 1;
+    const long long units = (long long)nr * NJB + (long long)nc * NIB;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < units; g += (long long)gridDim.x * 4) {
         const bool col = g >= (long long)nr * NJB;
         const long long gg = col ? g - (long long)nr * NJB : g;
         const int nblk = col ? NIB : NJB;
-        const int line = (col ? w.clist : w.rlist)[gg / nblk], t = (int)(gg % nblk);
+        const int line = __builtin_amdgcn_readfirstlane((col ? w.clist : w.rlist)[gg / nblk]), t = (int)(gg % nblk);
         const int N = col ? S : L, M = col ? L : S;        // own side / other side
         const int b = line / N, self = line % N;
         const float* pself = (col ? f1 : f0) + ((size_t)b * N + self) * C;
         const float* pother = (col ? f0 : f1) + (size_t)b * M * C;
         const bool self_masked = mask0 && (col ? mask1 : mask0)[(size_t)b * N + self] == 0;
         const uint8_t* mother = mask0 ? (col ? mask0 : mask1) + (size_t)b * M : nullptr;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pself + c);
+            *reinterpret_cast<f32x4*>(sl + c) = (f32x4){div_scalar<RECIP>(v.x, sqrtC, inv_sqrtC), div_scalar<RECIP>(v.y, sqrtC, inv_sqrtC),
+                                                        div_scalar<RECIP>(v.z, sqrtC, inv_sqrtC), div_scalar<RECIP>(v.w, sqrtC, inv_sqrtC)};
+        }
+        wave_lds_fence_();
+        float acc[2] = {0.f, 0.f};
+        for (int ks = 0; ks < C / 32; ++ks) {
+            f32x4 a4[8];                                   // broadcast reads: the same 128 B for every lane
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a4[i] = *reinterpret_cast<const f32x4*>(sl + ks * 32 + 4 * i);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int o0 = t * 128 + half * 64;
+                f32x4 x[8];
+                wave_rows32_to_lanes(slab, lane, [&](int rr) { return pother + (size_t)min(o0 + rr, M - 1) * C + ks * 32; }, x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {   // fmaf(a, b, acc) == fmaf(b, a, acc): the chain is the oracle's whichever side the line is
+                    acc[half] = __builtin_fmaf(a4[i].x, div_scalar<RECIP>(x[i].x, sqrtC, inv_sqrtC), acc[half]);
+                    acc[half] = __builtin_fmaf(a4[i].y, div_scalar<RECIP>(x[i].y, sqrtC, inv_sqrtC), acc[half]);
+                    acc[half] = __builtin_fmaf(a4[i].z, div_scalar<RECIP>(x[i].z, sqrtC, inv_sqrtC), acc[half]);
+                    acc[half] = __builtin_fmaf(a4[i].w, div_scalar<RECIP>(x[i].w, sqrtC, inv_sqrtC), acc[half]);
+                }
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int o = t * 128 + half * 64 + lane;
+            float v = -INFINITY;                            // outside the matrix: never wins a max, adds exp(-inf) = 0
+            if (o < M) v = (self_masked || (mother && mother[o] == 0)) ? NEG_FILL : div_scalar<RECIP>(acc[half], T, invT);
+            xl[half * 64 + lane] = v;
+        }
+        wave_lds_fence_();
+        // replay of the tile kernel's reduction by lanes 0..3 (q = 2 * half + hi); the other lanes idle along
+        const int q = lane & 3, half = q >> 1, hi = q & 1;
         float x[32];
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
-            // e-th entry of this lane's run: rows -> column 32 hi + e of the half; columns -> row 32 ti + (r & 3) + 8 (r >> 2) + 4 hi
             const int local = col ? ((e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hi) : (32 * hi + e);
-            const int o = t * 128 + half * 64 + local;
-            float v = -INFINITY;                            // outside the matrix: never wins a max, adds exp(-inf) = 0
-            if (o < M) {
-                if (self_masked || (mother && mother[o] == 0)) v = NEG_FILL;
-                else v = col ? ds_exact_logit<RECIP>(pother + (size_t)o * C, pself, C, sqrtC, inv_sqrtC, T, invT)
-                             : ds_exact_logit<RECIP>(pself, pother + (size_t)o * C, C, sqrtC, inv_sqrtC, T, invT);
-            }
-            x[e] = v;
+            x[e] = xl[half * 64 + local];
         }
         float m = -INFINITY;
 #pragma unroll
@@ -750,11 +791,12 @@ __global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict_
         float tot = 0.f;
         if (ma > -INFINITY) tot += sa * __expf(ma - mm);
         if (mb > -INFINITY) tot += sb * __expf(mb - mm);
-        if (live && q == 0) {
-            const size_t o = ((size_t)b * nblk + t) * N + self;
-            (col ? w.cp_m : w.rp_m)[o] = mm;
-            (col ? w.cp_s : w.rp_s)[o] = tot;
+        if (lane == 0) {
+            const size_t oo = ((size_t)b * nblk + t) * N + self;
+            (col ? w.cp_m : w.rp_m)[oo] = mm;
+            (col ? w.cp_s : w.rp_s)[oo] = tot;
         }
+        wave_lds_fence_();   // xl is rewritten by the next unit
     }
 }
 
@@ -843,7 +885,7 @@ int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mas
     hipLaunchKernelGGL(ds_xnear_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, L, B * L, thr, kthr);
     hipLaunchKernelGGL(ds_xclaim_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, L, S);
     CASMTR_CHECK_LAUNCH();
-    // listed lines x blocks x 4 lanes, grid-strided; a typical batch lists a few dozen lines (~30 k threads)
+    // listed lines x blocks, one wave each, grid-strided
     if (recip)
         hipLaunchKernelGGL(ds_xstats_kernel<true>, dim3(1024), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC, 1.0f / sqrtC,
                            temperature, 1.0f / temperature, NJB, NIB);
@@ -860,6 +902,13 @@ int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mas
                            1.0f / sqrtC, temperature, 1.0f / temperature);
     hipLaunchKernelGGL(ds_xdecide_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, L, S, thr);
     CASMTR_CHECK_LAUNCH();
+    if (getenv("CASMTR_DS_DEBUG")) {   // diagnostic only: synchronises
+        int cnt[4] = {0, 0, 0, 0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(cnt, w.xcnt, sizeof cnt, hipMemcpyDeviceToHost);
+        fprintf(stderr, "ds_xdecide: %d borderline entries, %d rows + %d columns recomputed exactly (B = %d, L = %d, S = %d)\n", cnt[0], cnt[1],
+                cnt[2], B, L, S);
+    }
     return 0;
 }
 

@@ -39,6 +39,7 @@ struct P {
     unsigned long long* cyc;   // per block: s_memtime span
     int nq, pairs, items_per_pair;   // items per wave and pair
     int reads, bcast, rt, mfma, side;
+    int serial;   // 1: at most ONE 4 KB chunk in flight per wave (chunk n + 1 is issued when chunk n has landed, then n is consumed)
 };
 
 __global__ __launch_bounds__(64) void probe(const P p) {
@@ -79,6 +80,47 @@ __global__ __launch_bounds__(64) void probe(const P p) {
         }
     };
     unsigned long long t0 = 0;
+    if (p.serial) {
+        // chunk-granular pipeline: K0 K1 V0 V1 of item after item; in flight while chunk n is consumed: chunk n + 1 only
+        const long long nchunks = (long long)p.pairs * p.items_per_pair * 4;
+        auto base_of = [&](long long n) {
+            const int pr = (int)(n / (4ll * p.items_per_pair));
+            return p.kv + ((size_t)xcd * p.pairs + pr) * 2 * slice + (((n >> 1) & 1) ? slice : 0);
+        };
+        issue(base_of(0), 0);
+        for (long long n = 0; n < nchunks; ++n) {
+            if (n == 4) t0 = __builtin_readcyclecounter();
+            vmwait<0>();
+            if (n + 1 < nchunks) issue(base_of(n + 1), (int)((n + 1) & 1));
+            const int c = (int)(n & 1);
+            if (p.side && (n & 3) == 0) {
+                const size_t item = ((size_t)(n >> 2) * gridDim.x + blockIdx.x);
+                if (lane < 32) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(p.qstream + item * 128 + lane * 4);
+                    *reinterpret_cast<f32x4*>(p.ostream + item * 128 + lane * 4) = acc;
+                    acc.x += q.x;
+                } else if (lane < 48) acc.y += (float)p.idx[item * 16 + (lane - 32)];
+            }
+            for (int b = 0; b < p.bcast / 4; ++b) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(extra + ((lane & 3) * 2 + (lane >> 5)) * 36 + (b & 7) * 4);
+                acc.y += v.x; acc.w += v.z;
+            }
+            if (p.reads == 1 || (p.reads == 2 && !(n & 2))) read128(c); else if (p.reads == 2) read32(c);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mfmas(p.mfma / 4);
+            if (p.rt && (n & 3) == 1) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) extra[f * 68 + lane] = acc[f];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const f32x4 v = *reinterpret_cast<const f32x4*>(extra + (lane >> 4) * 68 + (lane & 15) * 4);
+                acc.x += v.y;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                *reinterpret_cast<f32x2*>(extra + ((lane >> 4) * 2) * 36 + 2 * (lane & 15)) = (f32x2){v.x, v.z};
+                *reinterpret_cast<f32x2*>(extra + ((lane >> 4) * 2 + 1) * 36 + 2 * (lane & 15)) = (f32x2){v.y, v.w};
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    } else
     for (int pr = 0; pr < p.pairs; ++pr) {
         const float* kb = p.kv + ((size_t)xcd * p.pairs + pr) * 2 * slice;
         const float* vb = kb + slice;
@@ -97,9 +139,12 @@ __global__ __launch_bounds__(64) void probe(const P p) {
                     acc.x += q.x;
                 } else if (lane < 48) acc.y += (float)p.idx[item * 16 + (lane - 32)];
             }
-            for (int b = 0; b < p.bcast / 2; ++b) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(extra + (lane & 3) * 36 + (b & 7) * 4);
-                acc.x += v.x; acc.z += v.w;
+            if (p.bcast) {   // 8 independent broadcast reads in flight together, as the kernel's query operand
+                f32x4 v[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[b] = *reinterpret_cast<const f32x4*>(extra + (lane & 3) * 36 + b * 4);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) { acc.x += v[b].x; acc.z += v[b].w; }
             }
             if (p.reads) { read128(0); read128(1); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -121,9 +166,12 @@ __global__ __launch_bounds__(64) void probe(const P p) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 vmwait<4>();
-                for (int b = 0; b < p.bcast / 4; ++b) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(extra + ((lane & 3) * 2 + (lane >> 5)) * 36 + (b & 7) * 4);
-                    acc.y += v.x; acc.w += v.z;
+                if (p.bcast) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v[b] = *reinterpret_cast<const f32x4*>(extra + ((lane & 3) * 2 + (lane >> 5)) * 36 + (4 * c + b) * 4);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { acc.y += v[b].x; acc.w += v[b].z; }
                 }
                 if (p.reads == 1) read128(c); else if (p.reads == 2) read32(c);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -148,42 +196,39 @@ int main(int argc, char** argv) {
     hipMalloc(&qs, n_items * 512); hipMalloc(&os, n_items * 512); hipMalloc(&idx, n_items * 64); hipMalloc(&sink, 4096);
     hipMalloc(&cyc, 8192 * 8);
     hipMemset(qs, 0, n_items * 512); hipMemset(idx, 0, n_items * 64);
-    struct Cfg { const char* what; int per_cu, lds, pairs, reads, bcast, rt, mfma, side; };
+    struct Cfg { const char* what; int per_cu, lds, pairs, reads, bcast, rt, mfma, side, serial; };
     const Cfg cfgs[] = {
-        {"dma only", 8, 8192, 1, 0, 0, 0, 0, 0},
-        {"dma only", 10, 8192, 1, 0, 0, 0, 0, 0},
-        {"dma only", 12, 8192, 1, 0, 0, 0, 0, 0},
-        {"dma only", 16, 8192, 1, 0, 0, 0, 0, 0},
-        {"dma only", 20, 8192, 1, 0, 0, 0, 0, 0},
-        {"+ b128 reads of every byte", 10, 8192, 1, 1, 0, 0, 0, 0},
-        {"+ b128 reads of every byte", 16, 8192, 1, 1, 0, 0, 0, 0},
-        {"+ b128 reads of every byte", 20, 8192, 1, 1, 0, 0, 0, 0},
-        {"+ K b128 / V b32 reads", 10, 8192, 1, 2, 0, 0, 0, 0},
-        {"+ K b128 / V b32 reads", 16, 8192, 1, 2, 0, 0, 0, 0},
-        {"+ 16 broadcast b128", 10, 9600, 1, 2, 16, 0, 0, 0},
-        {"+ 16 broadcast b128", 16, 9600, 1, 2, 16, 0, 0, 0},
-        {"+ softmax round trip", 10, 9600, 1, 2, 16, 1, 0, 0},
-        {"+ softmax round trip", 16, 9600, 1, 2, 16, 1, 0, 0},
-        {"+ 64 mfma", 10, 9600, 1, 2, 16, 1, 64, 0},
-        {"+ 64 mfma", 16, 9600, 1, 2, 16, 1, 64, 0},
-        {"+ side streams", 10, 9600, 1, 2, 16, 1, 64, 1},
-        {"+ side streams", 16, 9600, 1, 2, 16, 1, 64, 1},
-        {"kernel-like, 8 pairs walked", 8, 11392, 8, 2, 16, 1, 64, 1},
-        {"kernel-like, 8 pairs walked", 10, 11392, 8, 2, 16, 1, 64, 1},
-        {"kernel-like, 8 pairs walked", 12, 11392, 8, 2, 16, 1, 64, 1},
-        {"kernel-like, 8 pairs walked", 14, 11392, 8, 2, 16, 1, 64, 1},
-        {"kernel-like LDS 9.6 KB, 8 pairs", 16, 9600, 8, 2, 16, 1, 64, 1},
-        {"dma only, 8 pairs walked", 10, 8192, 8, 0, 0, 0, 0, 0},
-        {"dma only, 8 pairs walked", 16, 8192, 8, 0, 0, 0, 0, 0},
-        {"dma only, 8 pairs walked", 20, 8192, 8, 0, 0, 0, 0, 0},
-        {"slim reads (8 b128 V, no bcast/rt), 8 pairs", 10, 9600, 8, 1, 8, 0, 64, 1},
-        {"slim reads (8 b128 V, no bcast/rt), 8 pairs", 16, 9600, 8, 1, 8, 0, 64, 1},
+        {"dma only", 10, 8192, 1, 0, 0, 0, 0, 0, 0},
+        {"dma only", 16, 8192, 1, 0, 0, 0, 0, 0, 0},
+        {"+ K b128 / V b32 reads", 10, 8192, 1, 2, 0, 0, 0, 0, 0},
+        {"+ 16 broadcast b128 (independent)", 10, 9600, 1, 2, 16, 0, 0, 0, 0},
+        {"+ 16 broadcast b128 (independent)", 16, 9600, 1, 2, 16, 0, 0, 0, 0},
+        {"+ softmax round trip", 10, 9600, 1, 2, 16, 1, 0, 0, 0},
+        {"+ softmax round trip", 16, 9600, 1, 2, 16, 1, 0, 0, 0},
+        {"+ 64 mfma", 10, 9600, 1, 2, 16, 1, 64, 0, 0},
+        {"+ 64 mfma", 16, 9600, 1, 2, 16, 1, 64, 0, 0},
+        {"+ side streams", 10, 9600, 1, 2, 16, 1, 64, 1, 0},
+        {"+ side streams", 16, 9600, 1, 2, 16, 1, 64, 1, 0},
+        {"kernel-like, 8 pairs walked", 10, 11392, 8, 2, 16, 1, 64, 1, 0},
+        {"kernel-like, 8 pairs walked", 12, 11392, 8, 2, 16, 1, 64, 1, 0},
+        {"kernel-like, 8 pairs walked", 14, 11392, 8, 2, 16, 1, 64, 1, 0},
+        {"kernel-like LDS 9.6 KB, 8 pairs", 16, 9600, 8, 2, 16, 1, 64, 1, 0},
+        {"dma only, 8 pairs walked", 10, 8192, 8, 0, 0, 0, 0, 0, 0},
+        {"dma only, 8 pairs walked", 16, 8192, 8, 0, 0, 0, 0, 0, 0},
+        {"dma only, 8 pairs, ONE chunk in flight", 10, 8192, 8, 0, 0, 0, 0, 0, 1},
+        {"dma only, 8 pairs, ONE chunk in flight", 16, 8192, 8, 0, 0, 0, 0, 0, 1},
+        {"dma only, 8 pairs, ONE chunk in flight", 20, 8192, 8, 0, 0, 0, 0, 0, 1},
+        {"dma only, 1 region, ONE chunk in flight", 16, 8192, 1, 0, 0, 0, 0, 0, 1},
+        {"dma only, 1 region, ONE chunk in flight", 20, 8192, 1, 0, 0, 0, 0, 0, 1},
+        {"kernel-like, 8 pairs, ONE chunk in flight", 12, 9600, 8, 2, 16, 1, 64, 1, 1},
+        {"kernel-like, 8 pairs, ONE chunk in flight", 16, 9600, 8, 2, 16, 1, 64, 1, 1},
+        {"kernel-like, 1 region, ONE chunk in flight", 16, 9600, 1, 2, 16, 1, 64, 1, 1},
     };
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     for (const Cfg& c : cfgs) {
         P p{};
         p.kv = kv; p.qstream = qs; p.ostream = os; p.idx = idx; p.sink = sink; p.cyc = cyc; p.nq = nq;
-        p.pairs = c.pairs; p.reads = c.reads; p.bcast = c.bcast; p.rt = c.rt; p.mfma = c.mfma; p.side = c.side;
+        p.pairs = c.pairs; p.reads = c.reads; p.bcast = c.bcast; p.rt = c.rt; p.mfma = c.mfma; p.side = c.side; p.serial = c.serial;
         const int blocks = 256 * c.per_cu;
         p.items_per_pair = 2704 * 8 * 8 / blocks / c.pairs;
         const double items = (double)blocks * p.items_per_pair * c.pairs;
