@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcasmtr_hip.so")
+LIB_PATH = os.environ.get("CASMTR_LIB_PATH") or os.path.join(_HERE, "lib", "libcasmtr_hip.so")   # override: A/B of build variants (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 ERR_UNSUPPORTED = 1001
 

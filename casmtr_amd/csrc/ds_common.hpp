@@ -9,7 +9,8 @@
 #define DS_BK 32
 #define DS_CAND_CAP 8        // near-tie candidates kept per row / column; more -> the whole call falls back to the exact GEMM
 #define DS_X_CAP 8192        // borderline entries (confidence near thr / near a row or column runner-up) re-decided exactly per call
-#define DS_XL_CAP 8192       // rows / columns whose softmax statistics are recomputed with the exact chain for them
+#define DS_XL_PCAP 1024      // rows (and columns) per image pair whose softmax statistics are recomputed with the exact chain
+#define DS_XL_G 8            // listed lines of one pair and side that share one pass over the other side's features
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
@@ -25,7 +26,8 @@ struct DsWs {  // carve of stats_ws
     unsigned *namax, *nbmax;         // [B] max row norm (float bits)
     int* ovf;                        // != 0: some row / column had more than DS_CAND_CAP candidates (or a borderline list overflowed)
     // exact re-decision of borderline match-list entries (ds_split.hip, "match list exact by construction")
-    int* xcnt;                       // [4]: entries, needed rows, needed columns, spare
+    int* xcnt;                       // [4]: entries (the rest spare)
+    int* xln;                        // [2][B]: listed rows / listed columns per pair
     unsigned char *rneed, *cneed;    // [B*L], [B*S] line already on rlist / clist
     unsigned char* rdec;             // [B*L] bit 0: the row's match decision was re-made exactly, bit 1: it is a match
     char* zero_end;
@@ -41,7 +43,7 @@ struct DsWs {  // carve of stats_ws
     int *rcand, *ccand;              // [B*L][CAP], [B*S][CAP]
     int* xent;                       // [DS_X_CAP][2] (global row b*L+i, column j)
     float* xcf;                      // [DS_X_CAP] exact confidence of the entry
-    int *rlist, *clist;              // [DS_XL_CAP] global row ids b*L+i / column ids b*S+j
+    int *rlist, *clist;              // [B][DS_XL_PCAP] row / column indices within the pair
     int* rdec_j;                     // [B*L] exactly re-decided rows: the row's best column ...
     float* rdec_cf;                  // [B*L] ... and its exact confidence
     _Float16 *imgA, *imgB;           // tile images [B][NIB][C/32][4 kg][2 parts][128 rows][8]
@@ -67,7 +69,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
     if (C > 0) {
         CARVE(rcnt, int, (size_t)B * L); CARVE(ccnt, int, (size_t)B * S);
         CARVE(namax, unsigned, B); CARVE(nbmax, unsigned, B); CARVE(ovf, int, 1);
-        CARVE(xcnt, int, 4); CARVE(rneed, unsigned char, (size_t)B * L); CARVE(cneed, unsigned char, (size_t)B * S);
+        CARVE(xcnt, int, 4); CARVE(xln, int, 2 * (size_t)B); CARVE(rneed, unsigned char, (size_t)B * L); CARVE(cneed, unsigned char, (size_t)B * S);
         CARVE(rdec, unsigned char, (size_t)B * L);
     }
     if (w) w->zero_end = base + off;
@@ -80,7 +82,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
         CARVE(rthr, float, (size_t)B * L); CARVE(cthr, float, (size_t)B * S);
         CARVE(cg_m, float, (size_t)B * NIB * 8 * S);
         CARVE(rcand, int, (size_t)B * L * DS_CAND_CAP); CARVE(ccand, int, (size_t)B * S * DS_CAND_CAP);
-        CARVE(xent, int, 2 * DS_X_CAP); CARVE(xcf, float, DS_X_CAP); CARVE(rlist, int, DS_XL_CAP); CARVE(clist, int, DS_XL_CAP);
+        CARVE(xent, int, 2 * DS_X_CAP); CARVE(xcf, float, DS_X_CAP); CARVE(rlist, int, (size_t)B * DS_XL_PCAP); CARVE(clist, int, (size_t)B * DS_XL_PCAP);
         CARVE(rdec_j, int, (size_t)B * L); CARVE(rdec_cf, float, (size_t)B * L);
         CARVE(imgA, _Float16, (size_t)B * Lp * C * 2); CARVE(imgB, _Float16, (size_t)B * Sp * C * 2);
     }

@@ -663,13 +663,13 @@ __global__ __launch_bounds__(256) void ds_xnear_kernel(DsWs w, int L, int total,
     if (fabsf(cf - thr) <= band * fmaxf(cf, thr)) ds_x_append(w, t, (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)));
 }
 
-// (2) thread per listed entry: its row and its column need exact statistics (each line is claimed once)
-__global__ __launch_bounds__(256) void ds_xclaim_kernel(DsWs w, int L, int S) {
+// (2) thread per listed entry: its row and its column need exact statistics (each line is claimed once, lists per pair)
+__global__ __launch_bounds__(256) void ds_xclaim_kernel(DsWs w, int B, int L, int S) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(w.xcnt[0], DS_X_CAP);
     if (t >= n) return;
     const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
-    const int co = (ro / L) * S + j;
+    const int b = ro / L, co = b * S + j;
     // byte flags inside 4-byte words: claim with an atomic OR on the containing word
     auto claim = [](unsigned char* flags, int idx) {
         unsigned* wp = reinterpret_cast<unsigned*>(flags) + (idx >> 2);
@@ -677,12 +677,245 @@ __global__ __launch_bounds__(256) void ds_xclaim_kernel(DsWs w, int L, int S) {
         return (atomicOr(wp, bit) & bit) == 0;
     };
     if (claim(w.rneed, ro)) {
-        const int slot = atomicAdd(w.xcnt + 1, 1);
-        if (slot < DS_XL_CAP) w.rlist[slot] = ro; else *w.ovf = 1;
+        const int slot = atomicAdd(w.xln + b, 1);
+        if (slot < DS_XL_PCAP) w.rlist[(size_t)b * DS_XL_PCAP + slot] = ro - b * L; else *w.ovf = 1;
     }
     if (claim(w.cneed, co)) {
-        const int slot = atomicAdd(w.xcnt + 2, 1);
-        if (slot < DS_XL_CAP) w.clist[slot] = co; else *w.ovf = 1;
+        const int slot = atomicAdd(w.xln + B + b, 1);
+        if (slot < DS_XL_PCAP) w.clist[(size_t)b * DS_XL_PCAP + slot] = j; else *w.ovf = 1;
+    }
+}
+
+// (3) exact (max, sum exp) partials of the listed lines over one 128-wide block, in ds_tile_epilogue<RECIP, false>'s order.
+// Workgroup = (pair, side, group of up to 32 listed lines, four consecutive blocks); its four waves take one block each and ALL the
+// group's lines: the lines' own rows sit once in LDS (pre-scaled, read as broadcasts), the block's 128 rows of the OTHER side pass
+// through the wave's transposition slab once (32 channels at a time, coalesced 128-byte rows, the next step's rows in flight), and
+// the wave extends 2 x 32 chains -- lane <-> entry (two halves of 64), c ascending across the chunks = the oracle's chain.  With ~22
+// lines per list the whole call is ONE round of ~340 workgroups whose inner loops are long uninterrupted FMA streams.
+// (History, all measured in the bench step with ~350 listed lines: a lane-per-row walk per line 1.4 ms (texture-address bound); a wave
+// per line 0.7 ms (each pass re-reads the other side's 11 MB at a 1 KB stride); a wave per 8 lines, with and without a shared slab,
+// 0.16-0.24 ms: two or more rounds of short units whose per-step latency -- transposition, barrier, a broadcast read in front of every
+// four FMAs -- was never covered; spilled accumulators and a scheduler that hoisted the next transposition above the current chains
+// cost another 2x on the way.)  Then four lanes per line replay what one LANE of the tile kernel reduces, from the logits parked in LDS:
+//   rows:    wave wc = half of the tile covers columns 64 wc .. 64 wc + 63; its lane (hi, row) scans columns 32 hi + c, c ascending;
+//   columns: wave wr = half covers rows 64 wr .. 64 wr + 63; its lane (hi, col) scans rows 32 ti + (r & 3) + 8 (r >> 2) + 4 hi in
+//            (ti, r) order --
+// the lane pair (hi = 0, 1) shares its maximum and adds its sums, and the two halves combine as the tile kernel's step 4 does.
+#define DS_XL_GB 32   // lines per workgroup unit
+template <bool RECIP>
+__global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                        const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
+                                                        int B, int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT,
+                                                        int NJB, int NIB) {
+    constexpr int GB = DS_XL_GB;
+    extern __shared__ __attribute__((aligned(16))) float xs_smem[];
+    float* sl = xs_smem;                                   // [GB][256] the lines' own rows, scaled by 1 / sqrt(C) (C <= 256); shared by the 4 waves
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* slab = xs_smem + GB * 256 + wave * CASMTR_SLAB_FLOATS;   // wave-private transposition slab; later the logits of 8 lines
+    long long g = blockIdx.x;
+    long long base = 0;
+    // list lengths: one load per 64 lists (lane <-> list): the counters were written by device-scope atomics, every first read misses
+    int cnts = 0;
+    for (int sb = 0; sb < 2 * B; ++sb) {
+        if ((sb & 63) == 0) cnts = sb + lane < 2 * B ? min(w.xln[sb + lane], DS_XL_PCAP) : 0;
+        const bool col = sb >= B;
+        const int b = col ? sb - B : sb;
+        const int cnt = __shfl(cnts, sb & 63), nblk = col ? NIB : NJB, nq = (nblk + 3) >> 2;
+        const long long nu = (long long)((cnt + GB - 1) / GB) * nq;
+        for (; g < base + nu; g += gridDim.x) {
+            const int grp = (int)((g - base) / nq), t = (int)((g - base) % nq) * 4 + wave;
+            const int ng = min(GB, cnt - grp * GB);        // lines of this group
+            const bool live = t < nblk;                    // this wave has a block
+            const int* list = (col ? w.clist : w.rlist) + (size_t)b * DS_XL_PCAP + grp * GB;
+            const int N = col ? S : L, M = col ? L : S;    // own side / other side
+            const float* pown = (col ? f1 : f0) + (size_t)b * N * C;
+            const float* pother = (col ? f0 : f1) + (size_t)b * M * C;
+            const uint8_t* mown = mask0 ? (col ? mask1 : mask0) + (size_t)b * N : nullptr;
+            const uint8_t* mother = mask0 ? (col ? mask0 : mask1) + (size_t)b * M : nullptr;
+            // the group's line indices: ONE load (lane k <- entry k); wave v stages lines 8 v .. 8 v + 7 by independent loads
+            const int mine = list[lane < ng ? lane : 0];
+            {
+                f32x4 rv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int self = __shfl(mine, 8 * wave + k);
+                    rv[k] = lane * 4 < C ? *reinterpret_cast<const f32x4*>(pown + (size_t)self * C + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    *reinterpret_cast<f32x4*>(sl + (8 * wave + k) * 256 + lane * 4) =
+                        (f32x4){div_scalar<RECIP>(rv[k].x, sqrtC, inv_sqrtC), div_scalar<RECIP>(rv[k].y, sqrtC, inv_sqrtC),
+                                div_scalar<RECIP>(rv[k].z, sqrtC, inv_sqrtC), div_scalar<RECIP>(rv[k].w, sqrtC, inv_sqrtC)};
+            }
+            const bool selfmask = mown && mown[mine] == 0;   // lane k: line k of the group is a padded row / column
+            __syncthreads();
+            if (live) {
+                float acc[2][GB];
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int k = 0; k < GB; ++k) acc[half][k] = 0.f;
+                auto load_rows = [&](int step, f32x4 (&v)[8]) {
+                    const int ks = step >> 1, o0 = t * 128 + (step & 1) * 64;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        v[jj] = *reinterpret_cast<const f32x4*>(pother + (size_t)min(o0 + 8 * jj + (lane >> 3), M - 1) * C + ks * 32 + (lane & 7) * 4);
+                };
+                f32x4 v[8];
+                load_rows(0, v);
+                for (int ks = 0; ks < C / 32; ++ks)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {   // compile-time half: acc[step & 1][k] would make the accumulators a scratch array
+                    const int step = 2 * ks + hf;
+                    f32x4 x[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) *reinterpret_cast<f32x4*>(slab + (8 * jj + (lane >> 3)) * 36 + (lane & 7) * 4) = v[jj];
+                    wave_lds_fence_();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const f32x4*>(slab + lane * 36 + i * 4);
+                    wave_lds_fence_();
+                    if (step + 1 < 2 * (C / 32)) load_rows(step + 1, v);   // ~2 us away (HBM / Infinity Cache at a 1 KB stride); this step runs longer
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        x[i].x = div_scalar<RECIP>(x[i].x, sqrtC, inv_sqrtC); x[i].y = div_scalar<RECIP>(x[i].y, sqrtC, inv_sqrtC);
+                        x[i].z = div_scalar<RECIP>(x[i].z, sqrtC, inv_sqrtC); x[i].w = div_scalar<RECIP>(x[i].w, sqrtC, inv_sqrtC);
+                    }
+                    // lines in groups of 8 (a group beyond the list is skipped), channels outer / lines inner inside a group: the 8
+                    // broadcast reads of a channel quad are independent of each other and of the 8 chains they feed
+#pragma unroll
+                    for (int gq = 0; gq < GB / 8; ++gq) {
+                        if (8 * gq < ng) {
+                            // the broadcast reads of channel quad i + 1 are issued before the chains of quad i run (double-buffered by hand;
+                            // the fence keeps the scheduler from hoisting a whole step's reads: 256 live VGPRs, spills)
+                            f32x4 a4n[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) a4n[k] = *reinterpret_cast<const f32x4*>(sl + (8 * gq + k) * 256 + ks * 32);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                f32x4 a4[8];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) a4[k] = a4n[k];
+                                asm volatile("" ::: "memory");
+                                if (i < 7) {
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) a4n[k] = *reinterpret_cast<const f32x4*>(sl + (8 * gq + k) * 256 + ks * 32 + 4 * (i + 1));
+                                }
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {   // fmaf(a, b, acc) == fmaf(b, a, acc): the oracle's chain whichever side the line is on
+                                    // v_fmac_f32 by hand: hipcc SLP-packs the chains of two lines into v_pk_fma_f32 otherwise
+                                    float a_ = acc[hf][8 * gq + k];
+                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].x), "v"(x[i].x));
+                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].y), "v"(x[i].y));
+                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].z), "v"(x[i].z));
+                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].w), "v"(x[i].w));
+                                    acc[hf][8 * gq + k] = a_;
+                                }
+                            }
+                        }
+                    }
+                    // the chains of this step finish HERE, before the next step's slab writes (which wait for the prefetched rows)
+                    asm volatile("" : "+v"(acc[hf][0]), "+v"(acc[hf][8]), "+v"(acc[hf][16]), "+v"(acc[hf][24]) :: "memory");
+                }
+                // ---- the tile kernel's reduction, 8 lines at a time: logits -> slab (as [8][128]), lanes 4 k + q replay line k
+#pragma unroll
+                for (int gq = 0; gq < GB / 8; ++gq) {
+                    if (8 * gq < ng) {
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int o = t * 128 + half * 64 + lane;
+                            const bool om = mother && o < M && mother[o] == 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                float vv = -INFINITY;           // outside the matrix: never wins a max, adds exp(-inf) = 0
+                                const bool sm_ = __shfl((int)selfmask, 8 * gq + k) != 0;
+                                if (o < M) vv = (om || sm_) ? NEG_FILL : div_scalar<RECIP>(acc[half][8 * gq + k], T, invT);
+                                slab[k * 128 + half * 64 + lane] = vv;
+                            }
+                        }
+                        wave_lds_fence_();
+                        const int k = lane >> 2, q = lane & 3, half = q >> 1, hi = q & 1;
+                        const float* xk = slab + (k < 8 ? k : 0) * 128;
+                        float xe[32];
+#pragma unroll
+                        for (int e = 0; e < 32; ++e) {
+                            const int local = col ? ((e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hi) : (32 * hi + e);
+                            xe[e] = xk[half * 64 + local];
+                        }
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int e = 0; e < 32; ++e) m = xe[e] > m ? xe[e] : m;
+                        const float pm = __shfl_xor(m, 1);
+                        m = pm > m ? pm : m;
+                        float sm = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 32; ++e) sm += __expf(xe[e] - m);
+                        sm += __shfl_xor(sm, 1);
+                        // step 4 of the tile epilogue: halves 0 and 1
+                        const float mo = __shfl_xor(m, 2), so = __shfl_xor(sm, 2);
+                        const float ma = half ? mo : m, mb = half ? m : mo, sa = half ? so : sm, sb2 = half ? sm : so;
+                        const float mm = mb > ma ? mb : ma;
+                        float tot = 0.f;
+                        if (ma > -INFINITY) tot += sa * __expf(ma - mm);
+                        if (mb > -INFINITY) tot += sb2 * __expf(mb - mm);
+                        const int selfk = __shfl(mine, 8 * gq + (k < 8 ? k : 0));
+                        if (q == 0 && k < 8 && 8 * gq + k < ng) {
+                            const size_t oo = ((size_t)b * nblk + t) * N + selfk;
+                            (col ? w.cp_m : w.rp_m)[oo] = mm;
+                            (col ? w.cp_s : w.rp_s)[oo] = tot;
+                        }
+                        wave_lds_fence_();
+                    }
+                }
+            }
+            __syncthreads();   // sl is rewritten by the next unit
+        }
+        base += nu;
+    }
+}
+
+// (4) wave per listed line: block partials -> (max, sum) exactly as ds_reduce_kernel (sum over the blocks in ascending order; the
+// terms are formed by the lanes in parallel and added up in order by lane 0); next_conf = 1 / sum follows
+__global__ __launch_bounds__(256) void ds_xreduce_kernel(DsWs w, int B, int L, int S, int NJB, int NIB, float* __restrict__ next_conf01,
+                                                         float* __restrict__ next_conf10) {
+    __shared__ float terms[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the per-pair list lengths: one load (lane <-> list), then only the listed lines are visited
+    for (int sb0 = 0; sb0 < 2 * B; sb0 += 64) {
+    const int mycnt = sb0 + lane < 2 * B ? min(w.xln[sb0 + lane], DS_XL_PCAP) : 0;
+    for (int s2 = 0; s2 < min(64, 2 * B - sb0); ++s2) {
+    const int sb = sb0 + s2, cnt = __shfl(mycnt, s2);
+    const int nW = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
+    for (int k = (wg + nW - (sb * 64) % nW) % nW; k < cnt; k += nW) {   // list sb starts at wave 64 sb: the lists' lines run side by side
+        const bool col = sb >= B;
+        const int b = col ? sb - B : sb;
+        const int self = (col ? w.clist : w.rlist)[(size_t)b * DS_XL_PCAP + k];
+        const int N = col ? S : L, nblk = col ? NIB : NJB;
+        const int line = b * N + self;
+        const float* pm = (col ? w.cp_m : w.rp_m) + (size_t)b * nblk * N + self;
+        const float* ps = (col ? w.cp_s : w.rp_s) + (size_t)b * nblk * N + self;
+        float pmv[4], psv[4], m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = lane + 64 * u;
+            pmv[u] = kk < nblk ? pm[(size_t)kk * N] : -INFINITY;
+            psv[u] = kk < nblk ? ps[(size_t)kk * N] : 0.f;
+            m = fmaxf(m, pmv[u]);
+        }
+        m = wave_max_f32(m);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) terms[wave][lane + 64 * u] = psv[u] * __expf(pmv[u] - m);
+        wave_lds_fence_();
+        if (lane == 0) {
+            float s = 0.f;
+            for (int kk = 0; kk < nblk; ++kk) s += terms[wave][kk];
+            (col ? w.cmax : w.rmax)[line] = m;
+            (col ? w.csum : w.rsum)[line] = s;
+            (col ? next_conf10 : next_conf01)[line] = 1.0f / s;
+        }
+        wave_lds_fence_();
+    }
+    }
     }
 }
 
@@ -701,181 +934,85 @@ __device__ __forceinline__ float ds_exact_logit(const float* __restrict__ pa, co
     return div_scalar<RECIP>(acc, T, invT);
 }
 
-// (3) exact (max, sum exp) partial of one listed line over one 128-wide block, in ds_tile_epilogue<RECIP, false>'s order.
-// One wave per (line, block).  The 128 exact logits: lane <-> entry (two halves of 64), the other side's rows through the wave's
-// transposition slab 32 channels at a time (coalesced 128-byte rows; a lane-per-row walk of 10 816 x 1 KB rows per line was
-// texture-address bound: 1.4 ms per step), the chain extended c-ascending across the chunks = the oracle's chain.  Then lanes
-// q = 2 * half + hi < 4 replay what one LANE of the tile kernel reduces, from the logits parked in LDS --
-//   rows:    wave wc = half of the tile covers columns 64 wc .. 64 wc + 63; its lane (hi, row) scans columns 32 hi + c, c ascending;
-//   columns: wave wr = half covers rows 64 wr .. 64 wr + 63; its lane (hi, col) scans rows 32 ti + (r & 3) + 8 (r >> 2) + 4 hi in
-//            (ti, r) order --
-// the lane pair (hi = 0, 1) shares its maximum and adds its sums, and the two halves combine as the tile kernel's step 4 does.
-template <bool RECIP>
-__global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
-                                                        const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
-                                                        int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT, int NJB,
-                                                        int NIB) {
-    __shared__ float slabs[4 * (CASMTR_SLAB_FLOATS + 128 + 256)];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* slab = slabs + wave * (CASMTR_SLAB_FLOATS + 128 + 256);
-    float* xl = slab + CASMTR_SLAB_FLOATS;                 // the block's 128 logits
-    float* sl = xl + 128;                                  // the line's own feature row, scaled by 1 / sqrt(C) (C <= 256)
-    const int nr = min(w.xcnt[1], DS_XL_CAP), nc = min(w.xcnt[2], DS_XL_CAP);
-    const long long units = (long long)nr * NJB + (long long)nc * NIB;
-    for (long long g = (long long)blockIdx.x * 4 + wave; g < units; g += (long long)gridDim.x * 4) {
-        const bool col = g >= (long long)nr * NJB;
-        const long long gg = col ? g - (long long)nr * NJB : g;
-        const int nblk = col ? NIB : NJB;
-        const int line = __builtin_amdgcn_readfirstlane((col ? w.clist : w.rlist)[gg / nblk]), t = (int)(gg % nblk);
-        const int N = col ? S : L, M = col ? L : S;        // own side / other side
-        const int b = line / N, self = line % N;
-        const float* pself = (col ? f1 : f0) + ((size_t)b * N + self) * C;
-        const float* pother = (col ? f0 : f1) + (size_t)b * M * C;
-        const bool self_masked = mask0 && (col ? mask1 : mask0)[(size_t)b * N + self] == 0;
-        const uint8_t* mother = mask0 ? (col ? mask0 : mask1) + (size_t)b * M : nullptr;
-        for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(pself + c);
-            *reinterpret_cast<f32x4*>(sl + c) = (f32x4){div_scalar<RECIP>(v.x, sqrtC, inv_sqrtC), div_scalar<RECIP>(v.y, sqrtC, inv_sqrtC),
-                                                        div_scalar<RECIP>(v.z, sqrtC, inv_sqrtC), div_scalar<RECIP>(v.w, sqrtC, inv_sqrtC)};
-        }
-        wave_lds_fence_();
-        float acc[2] = {0.f, 0.f};
-        for (int ks = 0; ks < C / 32; ++ks) {
-            f32x4 a4[8];                                   // broadcast reads: the same 128 B for every lane
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a4[i] = *reinterpret_cast<const f32x4*>(sl + ks * 32 + 4 * i);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int o0 = t * 128 + half * 64;
-                f32x4 x[8];
-                wave_rows32_to_lanes(slab, lane, [&](int rr) { return pother + (size_t)min(o0 + rr, M - 1) * C + ks * 32; }, x);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {   // fmaf(a, b, acc) == fmaf(b, a, acc): the chain is the oracle's whichever side the line is
-                    acc[half] = __builtin_fmaf(a4[i].x, div_scalar<RECIP>(x[i].x, sqrtC, inv_sqrtC), acc[half]);
-                    acc[half] = __builtin_fmaf(a4[i].y, div_scalar<RECIP>(x[i].y, sqrtC, inv_sqrtC), acc[half]);
-                    acc[half] = __builtin_fmaf(a4[i].z, div_scalar<RECIP>(x[i].z, sqrtC, inv_sqrtC), acc[half]);
-                    acc[half] = __builtin_fmaf(a4[i].w, div_scalar<RECIP>(x[i].w, sqrtC, inv_sqrtC), acc[half]);
-                }
-            }
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int o = t * 128 + half * 64 + lane;
-            float v = -INFINITY;                            // outside the matrix: never wins a max, adds exp(-inf) = 0
-            if (o < M) v = (self_masked || (mother && mother[o] == 0)) ? NEG_FILL : div_scalar<RECIP>(acc[half], T, invT);
-            xl[half * 64 + lane] = v;
-        }
-        wave_lds_fence_();
-        // replay of the tile kernel's reduction by lanes 0..3 (q = 2 * half + hi); the other lanes idle along
-        const int q = lane & 3, half = q >> 1, hi = q & 1;
-        float x[32];
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const int local = col ? ((e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hi) : (32 * hi + e);
-            x[e] = xl[half * 64 + local];
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) m = x[e] > m ? x[e] : m;
-        const float pm = __shfl_xor(m, 1);
-        m = pm > m ? pm : m;
-        float sm = 0.f;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) sm += __expf(x[e] - m);
-        sm += __shfl_xor(sm, 1);
-        // step 4 of the tile epilogue: halves 0 and 1
-        const float mo = __shfl_xor(m, 2), so = __shfl_xor(sm, 2);
-        const float ma = half ? mo : m, mb = half ? m : mo, sa = half ? so : sm, sb = half ? sm : so;
-        const float mm = mb > ma ? mb : ma;
-        float tot = 0.f;
-        if (ma > -INFINITY) tot += sa * __expf(ma - mm);
-        if (mb > -INFINITY) tot += sb * __expf(mb - mm);
-        if (lane == 0) {
-            const size_t oo = ((size_t)b * nblk + t) * N + self;
-            (col ? w.cp_m : w.rp_m)[oo] = mm;
-            (col ? w.cp_s : w.rp_s)[oo] = tot;
-        }
-        wave_lds_fence_();   // xl is rewritten by the next unit
-    }
-}
-
-// (4) thread per listed line: block partials -> (max, sum) exactly as ds_reduce_kernel; next_conf = 1 / sum follows
-__global__ __launch_bounds__(256) void ds_xreduce_kernel(DsWs w, int L, int S, int NJB, int NIB, float* __restrict__ next_conf01,
-                                                         float* __restrict__ next_conf10) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nr = min(w.xcnt[1], DS_XL_CAP), nc = min(w.xcnt[2], DS_XL_CAP);
-    if (t >= nr + nc) return;
-    const bool col = t >= nr;
-    const int line = col ? w.clist[t - nr] : w.rlist[t];
-    const int N = col ? S : L, nblk = col ? NIB : NJB;
-    const int b = line / N, self = line % N;
-    const float* pm = (col ? w.cp_m : w.rp_m) + (size_t)b * nblk * N + self;
-    const float* ps = (col ? w.cp_s : w.rp_s) + (size_t)b * nblk * N + self;
-    float m = pm[0];
-    for (int k = 1; k < nblk; ++k) {
-        const float x = pm[(size_t)k * N];
-        if (x > m) m = x;
-    }
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += ps[(size_t)k * N] * __expf(pm[(size_t)k * N] - m);
-    (col ? w.cmax : w.rmax)[line] = m;
-    (col ? w.csum : w.rsum)[line] = s;
-    (col ? next_conf10 : next_conf01)[line] = 1.0f / s;
-}
-
-// (5) thread per listed entry: exact confidence, the expression of ds_conf_kernel<false>
+// (5) wave per listed entry: exact confidence, the expression of ds_conf_kernel<false>.  The two feature rows come in by one coalesced
+// load each and sit in LDS, pre-scaled; the chain itself is sequential (every lane runs it on broadcast reads).  (A thread per entry
+// walking both rows 16 bytes at a time was 24 us of dependent memory latency.)
 template <bool RECIP>
 __global__ __launch_bounds__(256) void ds_xconf_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                        const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
                                                        int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= min(w.xcnt[0], DS_X_CAP)) return;
-    const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
-    const int b = ro / L, i = ro % L;
-    const size_t co = (size_t)b * S + j;
-    float x = NEG_FILL;
-    if (!(mask0 && (mask0[ro] == 0 || mask1[co] == 0)))
-        x = ds_exact_logit<RECIP>(f0 + (size_t)ro * C, f1 + co * C, C, sqrtC, inv_sqrtC, T, invT);
-    const float rm = w.rmax[ro], rinv = 1.0f / w.rsum[ro], cm = w.cmax[co], cinv = 1.0f / w.csum[co];
-    const float p01 = __expf(x - rm) * rinv;
-    const float p10 = __expf(x - cm) * cinv;
-    w.xcf[t] = p10 * p01;
-    (void)i;
+    __shared__ __attribute__((aligned(16))) float rows[4][2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = min(w.xcnt[0], DS_X_CAP);
+    for (int t = blockIdx.x * 4 + wave; t < n; t += gridDim.x * 4) {
+        const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
+        const int b = ro / L;
+        const size_t co = (size_t)b * S + j;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 va = lane * 4 < C ? *reinterpret_cast<const f32x4*>(f0 + (size_t)ro * C + lane * 4) : z;
+        const f32x4 vb = lane * 4 < C ? *reinterpret_cast<const f32x4*>(f1 + co * C + lane * 4) : z;
+        const float rm = w.rmax[ro], rs = w.rsum[ro], cm = w.cmax[co], cs = w.csum[co];
+        const bool masked = mask0 && (mask0[ro] == 0 || mask1[co] == 0);
+        *reinterpret_cast<f32x4*>(&rows[wave][0][lane * 4]) = (f32x4){div_scalar<RECIP>(va.x, sqrtC, inv_sqrtC), div_scalar<RECIP>(va.y, sqrtC, inv_sqrtC),
+                                                                      div_scalar<RECIP>(va.z, sqrtC, inv_sqrtC), div_scalar<RECIP>(va.w, sqrtC, inv_sqrtC)};
+        *reinterpret_cast<f32x4*>(&rows[wave][1][lane * 4]) = (f32x4){div_scalar<RECIP>(vb.x, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.y, sqrtC, inv_sqrtC),
+                                                                      div_scalar<RECIP>(vb.z, sqrtC, inv_sqrtC), div_scalar<RECIP>(vb.w, sqrtC, inv_sqrtC)};
+        wave_lds_fence_();
+        float acc = 0.f;
+        for (int c = 0; c < C; c += 4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(&rows[wave][0][c]), b4 = *reinterpret_cast<const f32x4*>(&rows[wave][1][c]);
+            acc = __builtin_fmaf(a4.x, b4.x, acc);
+            acc = __builtin_fmaf(a4.y, b4.y, acc);
+            acc = __builtin_fmaf(a4.z, b4.z, acc);
+            acc = __builtin_fmaf(a4.w, b4.w, acc);
+        }
+        const float x = masked ? NEG_FILL : div_scalar<RECIP>(acc, T, invT);
+        const float rinv = 1.0f / rs, cinv = 1.0f / cs;
+        const float p01 = __expf(x - rm) * rinv;
+        const float p10 = __expf(x - cm) * cinv;
+        if (lane == 0) w.xcf[t] = p10 * p01;
+        wave_lds_fence_();
+    }
 }
 
-// (6) thread per listed entry e = (i, j): is e the exact best of row i (first column among equal values) and does it satisfy
+// (6) wave per listed entry e = (i, j): is e the exact best of row i (first column among equal values) and does it satisfy
 // conf > thr and conf == column maximum?  Entries of row i / column j that are NOT listed lie below the band of the line's
-// approximate best; so if that best itself is not listed, nothing listed can be the line's maximum.
+// approximate best; so if that best itself is not listed, nothing listed can be the line's maximum.  The lanes share the walk over
+// the list (a thread per entry walking the whole list was 37 us of serial LDS round trips on one CU).
 __global__ __launch_bounds__(256) void ds_xdecide_kernel(DsWs w, int L, int S, float thr) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = min(w.xcnt[0], DS_X_CAP);
-    if (t >= n) return;
-    const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
-    const int b = ro / L;
-    const size_t co = (size_t)b * S + j;
-    const float cf = w.xcf[t];
-    const int jbest = (int)(0xFFFFFFFFu - (unsigned)(w.rbest[ro] & 0xFFFFFFFFu));
-    const int ibest = (int)(0xFFFFFFFFu - (unsigned)(w.cbest[co] & 0xFFFFFFFFu));
-    bool row_listed = false, col_listed = false;   // the row's / the column's approximate best is on the list
-    bool row_win = true, col_win = true;
-    for (int k = 0; k < n; ++k) {
-        const int ro2 = w.xent[2 * k], j2 = w.xent[2 * k + 1];
-        const float c2 = w.xcf[k];
-        if (ro2 == ro) {
-            row_listed |= j2 == jbest;
-            if (c2 > cf || (c2 == cf && j2 < j)) row_win = false;   // rbest semantics: maximal value, first column
+    for (int t = blockIdx.x * 4 + wave; t < n; t += gridDim.x * 4) {
+        const int ro = w.xent[2 * t], j = w.xent[2 * t + 1];
+        const int b = ro / L;
+        const size_t co = (size_t)b * S + j;
+        const float cf = w.xcf[t];
+        const int jbest = (int)(0xFFFFFFFFu - (unsigned)(w.rbest[ro] & 0xFFFFFFFFu));
+        const int ibest = (int)(0xFFFFFFFFu - (unsigned)(w.cbest[co] & 0xFFFFFFFFu));
+        bool row_listed = false, col_listed = false;   // the row's / the column's approximate best is on the list
+        bool row_lose = false, col_lose = false;
+        for (int k = lane; k < n; k += 64) {
+            const int ro2 = w.xent[2 * k], j2 = w.xent[2 * k + 1];
+            const float c2 = w.xcf[k];
+            if (ro2 == ro) {
+                row_listed |= j2 == jbest;
+                row_lose |= c2 > cf || (c2 == cf && j2 < j);        // rbest semantics: maximal value, first column
+            }
+            if (j2 == j && ro2 >= b * L && ro2 < (b + 1) * L) {
+                col_listed |= ro2 - b * L == ibest;
+                col_lose |= c2 > cf;                                 // mutual maximum BY VALUE (coarse_matching.py:120-122)
+            }
         }
-        if (j2 == j && ro2 / L == b) {
-            col_listed |= (ro2 % L) == ibest;
-            if (c2 > cf) col_win = false;                             // mutual maximum BY VALUE (coarse_matching.py:120-122)
+        const bool rl = __ballot(row_listed) != 0ull, cl = __ballot(col_listed) != 0ull;
+        const bool rlose = __ballot(row_lose) != 0ull, clo = __ballot(col_lose) != 0ull;
+        if (!rl || rlose) continue;               // not this row's exact best (or the row is decided by an unlisted, clearly larger entry)
+        if (lane == 0) {
+            const bool ok = cf > thr && cl && !clo;
+            w.rdec_j[ro] = j;                      // duplicates of e write the same values
+            w.rdec_cf[ro] = cf;
+            w.rdec[ro] = ok ? 3 : 1;
         }
     }
-    if (!row_listed || !row_win) return;      // not this row's exact best (or the row is decided by an unlisted, clearly larger entry)
-    const bool ok = cf > thr && col_listed && col_win;
-    w.rdec_j[ro] = j;                          // duplicates of e write the same values
-    w.rdec_cf[ro] = cf;
-    w.rdec[ro] = ok ? 3 : 1;
 }
 
 int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L,
@@ -883,31 +1020,38 @@ int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mas
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C), kthr = 6.103515625e-05f / temperature;
     hipLaunchKernelGGL(ds_xnear_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, L, B * L, thr, kthr);
-    hipLaunchKernelGGL(ds_xclaim_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, L, S);
+    hipLaunchKernelGGL(ds_xclaim_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, B, L, S);
     CASMTR_CHECK_LAUNCH();
-    // listed lines x blocks, one wave each, grid-strided
-    if (recip)
-        hipLaunchKernelGGL(ds_xstats_kernel<true>, dim3(1024), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC, 1.0f / sqrtC,
+    // (pair, side, group of 32 listed lines, four blocks) units, one workgroup each, grid-strided: one round for the usual ~340 units
+    const size_t xs_lds = sizeof(float) * (DS_XL_GB * 256 + 4 * CASMTR_SLAB_FLOATS);
+    if (recip) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_xstats_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_lds);
+        hipLaunchKernelGGL(ds_xstats_kernel<true>, dim3(512), dim3(256), xs_lds, s, feat0, feat1, mask0, mask1, w, B, L, S, C, sqrtC, 1.0f / sqrtC,
                            temperature, 1.0f / temperature, NJB, NIB);
-    else
-        hipLaunchKernelGGL(ds_xstats_kernel<false>, dim3(1024), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC, 1.0f / sqrtC,
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_xstats_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_lds);
+        hipLaunchKernelGGL(ds_xstats_kernel<false>, dim3(512), dim3(256), xs_lds, s, feat0, feat1, mask0, mask1, w, B, L, S, C, sqrtC, 1.0f / sqrtC,
                            temperature, 1.0f / temperature, NJB, NIB);
-    hipLaunchKernelGGL(ds_xreduce_kernel, dim3(2 * DS_XL_CAP / 256), dim3(256), 0, s, w, L, S, NJB, NIB, next_conf01, next_conf10);
+    }
+    hipLaunchKernelGGL(ds_xreduce_kernel, dim3(256), dim3(256), 0, s, w, B, L, S, NJB, NIB, next_conf01, next_conf10);
     CASMTR_CHECK_LAUNCH();
     if (recip)
-        hipLaunchKernelGGL(ds_xconf_kernel<true>, dim3(DS_X_CAP / 256), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC,
+        hipLaunchKernelGGL(ds_xconf_kernel<true>, dim3(256), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC,
                            1.0f / sqrtC, temperature, 1.0f / temperature);
     else
-        hipLaunchKernelGGL(ds_xconf_kernel<false>, dim3(DS_X_CAP / 256), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC,
+        hipLaunchKernelGGL(ds_xconf_kernel<false>, dim3(256), dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, sqrtC,
                            1.0f / sqrtC, temperature, 1.0f / temperature);
-    hipLaunchKernelGGL(ds_xdecide_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, L, S, thr);
+    hipLaunchKernelGGL(ds_xdecide_kernel, dim3(256), dim3(256), 0, s, w, L, S, thr);
     CASMTR_CHECK_LAUNCH();
     if (getenv("CASMTR_DS_DEBUG")) {   // diagnostic only: synchronises
-        int cnt[4] = {0, 0, 0, 0};
+        int cnt[4] = {0, 0, 0, 0}, ln[128] = {0};
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(cnt, w.xcnt, sizeof cnt, hipMemcpyDeviceToHost);
-        fprintf(stderr, "ds_xdecide: %d borderline entries, %d rows + %d columns recomputed exactly (B = %d, L = %d, S = %d)\n", cnt[0], cnt[1],
-                cnt[2], B, L, S);
+        (void)hipMemcpy(ln, w.xln, sizeof(int) * (size_t)(2 * B < 128 ? 2 * B : 128), hipMemcpyDeviceToHost);
+        int nr = 0, ncol = 0;
+        for (int i = 0; i < B && i < 64; ++i) { nr += ln[i]; ncol += ln[B + i]; }
+        fprintf(stderr, "ds_xdecide: %d borderline entries, %d rows + %d columns recomputed exactly (B = %d, L = %d, S = %d)\n", cnt[0], nr,
+                ncol, B, L, S);
     }
     return 0;
 }

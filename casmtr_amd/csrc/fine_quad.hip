@@ -56,7 +56,7 @@ struct FineQArgs {
     float temp, w_level;
     int topk, B, h0, w0, h1, w1, H, Kp, nquads, lq1;
     unsigned div_magic;      // ceil(2^32 / (w1/2)): p / (w1/2) == umulhi(p, div_magic) for p < 2^22 (0: w1/2 == 1)
-    int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores
+    int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores, 8 one K/V slice for all pairs
 };
 
 __device__ __forceinline__ void ce_desc(unsigned& a, unsigned& b) {   // compare-exchange: a >= b afterwards
@@ -244,7 +244,7 @@ __device__ __forceinline__ void softmax_select(const FineQArgs& a, const f32x4 (
         if (rank >= a.topk) my_pos = 0;
         const int c = my_pos;
         out_sc = Pld[(f * 2 + (c & 1)) * PST + (c >> 1)];
-        const int par = t2[((c >> 2) & 1) * 16 + (c >> 3)];
+        const int par = t2[c >> 2];   // candidate c = 4 * parent slot + child
         const int qy1 = a.div_magic ? (int)__umulhi((unsigned)par, a.div_magic) : par;
         const int qx1 = par - qy1 * w1p;
         out_idx = (2 * qy1 + ((c >> 1) & 1)) * a.w1 + 2 * qx1 + (c & 1);   // absolute index on the h1 x w1 grid (:224)
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     constexpr int P_FLOATS = 8 * PST;
     constexpr int NV = 2 * NPASS;         // V chunks per item
     static_assert(P_FLOATS >= 4 * KS, "the transposition buffer aliases the probabilities");
-    constexpr int STG = 256;              // staging buffer of one item: q [4][32] (16-byte units XOR-swizzled) | parents [64] | final[parent] [64]
+    constexpr int STG = 256;              // staging buffer of one item: q [4][32] (16-byte units XOR-swizzled) | parents [32] | final[parent] [32] | unused
     constexpr int WAVE_FLOATS = 2048 + P_FLOATS + 2 * STG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // two INDEPENDENT waves per workgroup (no block barrier anywhere): LDS is granted in coarse granules, and one wave's ~11 KB
@@ -312,40 +312,61 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
         return true;
     };
     const unsigned stg_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(stg));
-    // lane constants of the 4 staging instructions (each: 64 lanes x 4 bytes, lane-linear destination)
-    unsigned qo[2];   // q: staging dword 64 k + lane = row r, physical unit pu, word wv  <-  logical unit pu ^ (r >> 1) (conflict-free A reads)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int pos = 64 * k + lane, r = pos >> 5, c = pos & 31;
-        qo[k] = (unsigned)((r * 32 + (((c >> 2) ^ (r >> 1)) * 4) + (c & 3)) * 4);
+    // The item's whole front end arrives by ONE global_load_lds_dwordx4 (round 5; four global_load_lds_dword before: an LDS-DMA
+    // wave-instruction costs the CU's texture-address path ~19 cycles whatever its width, tools/probes/dma_width.hip, so the four narrow
+    // ones were a sixth of an item's address-path time).  Lane l fills the 16-byte staging unit l:
+    //   units  0..31  q: child r = l / 8, physical unit l % 8 <- logical unit (l % 8) ^ (r >> 1) (conflict-free A-operand reads)
+    //   units 32..39  parents[0 .. 31] in list order (lists shorter than 32: the last 16-byte unit of the list again)
+    //   units 40..47  final[parent] row of this head (acc_in), 32 floats
+    //   units 48..63  unused (they re-read the lane-47 source)
+    // The three sources are different tensors, so the instruction takes a 64-bit address per lane:
+    //   address = lane base + qd * mulq + bq * mula,  qd = (b * H + h) * Lq + quad,  bq = b * Lq + quad.
+    unsigned long long sbase;
+    unsigned mulq, mula;
+    {
+        const int u = lane < 48 ? lane : 47;
+        if (u < 32) {
+            const int r = u >> 3, pu = u & 7;
+            sbase = (unsigned long long)a.q + (unsigned)(r * 128 + ((pu ^ (r >> 1)) * 16));
+            mulq = 512u; mula = 0u;
+        } else if ((u < 40 || !a.acc_in) && !(Kp & 3)) {
+            sbase = (unsigned long long)a.parents + (unsigned)(min((u - 32) & 7, Kp / 4 - 1) * 16);
+            mulq = (unsigned)(Kp * 4); mula = 0u;
+        } else if (u < 40 || !a.acc_in) {          // ragged lists (Kp % 4 != 0) come by their own dword instruction below: nothing to read here
+            sbase = (unsigned long long)a.q;
+            mulq = 512u; mula = 0u;
+        } else {
+            sbase = (unsigned long long)a.acc_in + (unsigned)(h * 128 + (u - 40) * 16);
+            mulq = 0u; mula = (unsigned)(HD * 4);
+        }
     }
-    const unsigned po = (unsigned)(min(2 * (lane & 15) + ((lane >> 4) & 1), Kp - 1) * 4);   // staging dword parity * 16 + j <- parent 2 j + parity
-    const unsigned ao = (unsigned)((lane & 31) * 4);
-    auto dma4 = [&](const void* base, unsigned off, unsigned dst) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(base), "s"(dst) : "memory");
-    };
-    auto prefetch = [&](const Item& it, int buf) {   // 4 (3 without acc_in) DMA instructions
-        const unsigned qd = (unsigned)((it.b * H + h) * Lq + it.quad);   // wave-uniform
+    auto prefetch = [&](const Item& it, int buf) {   // 1 DMA instruction
+        const unsigned qd = (unsigned)((it.b * H + h) * Lq + it.quad), bq = (unsigned)(it.b * Lq + it.quad);   // wave-uniform
+        const unsigned long long addr = sbase + (unsigned long long)qd * mulq + (unsigned long long)bq * mula;
         const unsigned dst = stg_lds + (unsigned)(buf * STG * 4);
-        dma4(a.q, qd * 512u + qo[0], dst);
-        dma4(a.q, qd * 512u + qo[1], dst + 256u);
-        dma4(a.parents, qd * (unsigned)(Kp * 4) + po, dst + 512u);
-        if (a.acc_in) dma4(a.acc_in, (unsigned)((it.b * Lq + it.quad) * HD + h * 32) * 4u + ao, dst + 768u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(addr), "s"(dst) : "memory");
+        if ((Kp & 3) && lane < 32) {   // a 16-byte read of the last list piece would run past the table's end: 4-byte pieces, lanes 0-31 only
+            const unsigned off = qd * (unsigned)(Kp * 4) + (unsigned)(min(lane, Kp - 1) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(a.parents), "s"(dst + 512u) : "memory");
+        }
     };
     unsigned voff[NPASS][8];   // DMA instruction j of pass p: source offset of this lane's 16 bytes (rows 64p + 8j + lane/8)
     auto stage_in = [&](int buf) {   // the staged parent list -> this lane's DMA offsets
+        // DMA instruction jj = 4 i + x of the item covers parent slots 2 jj (lanes 0-31) and 2 jj + 1 (lanes 32-63)
         const int* t2 = reinterpret_cast<const int*>(stg + buf * STG + 128);
+        const bool hh = lane >> 5;
 #pragma unroll
         for (int i = 0; i < 2 * NPASS; ++i) {
-            const int4 p4 = *reinterpret_cast<const int4*>(t2 + (lane >> 5) * 16 + 4 * i);
-            voff[i >> 1][(i & 1) * 4 + 0] = ((unsigned)p4.x << 9) + cK[0];
-            voff[i >> 1][(i & 1) * 4 + 1] = ((unsigned)p4.y << 9) + cK[1];
-            voff[i >> 1][(i & 1) * 4 + 2] = ((unsigned)p4.z << 9) + cK[2];
-            voff[i >> 1][(i & 1) * 4 + 3] = ((unsigned)p4.w << 9) + cK[3];
+            const int4 pa4 = *reinterpret_cast<const int4*>(t2 + 8 * i), pb4 = *reinterpret_cast<const int4*>(t2 + 8 * i + 4);
+            voff[i >> 1][(i & 1) * 4 + 0] = ((unsigned)(hh ? pa4.y : pa4.x) << 9) + cK[0];
+            voff[i >> 1][(i & 1) * 4 + 1] = ((unsigned)(hh ? pa4.w : pa4.z) << 9) + cK[1];
+            voff[i >> 1][(i & 1) * 4 + 2] = ((unsigned)(hh ? pb4.y : pb4.x) << 9) + cK[2];
+            voff[i >> 1][(i & 1) * 4 + 3] = ((unsigned)(hh ? pb4.w : pb4.z) << 9) + cK[3];
         }
     };
     // chunk c of pass p (rows 64p + 32c ..) of K (isv = 0) or V (isv = 1) of pair b -> ring slot c
-    const size_t pair_pitch = (size_t)H * a.lq1 * 128;                                  // floats between two pairs' slices
+    // (xflags & 8, timing experiment: every pair gathers from pair 0's slices -- no slice transitions in the L2; results are garbage)
+    const size_t pair_pitch = (a.xflags & 8) ? 0 : (size_t)H * a.lq1 * 128;             // floats between two pairs' slices
     const float* const k0 = a.key + (size_t)h * a.lq1 * 128 - 768;                       // this head's slice of pair 0, 3072 bytes low
     const float* const v0 = a.value + (size_t)h * a.lq1 * 128 - 768;
     auto issue = [&](int isv, auto pc, auto cc, int b) {
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             if constexpr (p == 0) {
                 flush();
                 if (more) prefetch(it_nx, cbuf ^ 1);   // lands under this item's K pass and softmax; consumed at its chunk NV - 2
-                acc_cur = a.acc_in ? qs[192 + (lane & 31)] : 0.f;   // final[parent] of the item for d = lane % 32 (:277)
+                acc_cur = a.acc_in ? qs[160 + (lane & 31)] : 0.f;   // final[parent] of the item for d = lane % 32 (:277)
             }
             f32x4 qa[8], kr[8];   // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row
 #pragma unroll
@@ -460,6 +481,9 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             asm volatile("" : "+v"(lg[p]));   // keep the pass's arithmetic inside the pass
         });
         // ================================================================== softmax (+ top-k), one series (child) per 16-lane row
+        // (round 5: a softmax straight from the K pass's lane <-> candidate layout -- whole-wave reductions by DPP + permlane swaps, no
+        //  transposition through LDS, one fence instead of three -- measured 215 against 187 us per launch at the finest level: the
+        //  eight 64-lane reductions are a longer dependent chain than the LDS round trips they replace)
         softmax_select<NPASS, EXACT, FULL>(a, lg, Pld, t2, lane, K, w1p, pend_sc, pend_idx);
         // ================================================================== V chunks; then the next item's K pass 0
         f32x4 acc[4];

@@ -511,7 +511,8 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
                                              int B, int L, int S, int C, casmtr_stream_t stream) {
     if (C % DS_BK != 0 || (mask0 == nullptr) != (mask1 == nullptr)) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || L <= 0 || S <= 0) return 0;
-    if (C > 256)   // the exact re-decision stages a feature row of <= 256 channels in LDS (every shipped config: C = 256): wider features take
+    if (C > 256 || (C & 63) || L > 32768 || S > 32768)   // the exact re-decision stages a feature row of <= 256 channels in LDS and <= 256 block partials per
+                   // line (every shipped config: C = 256, 10 816 tokens): wider features / larger grids take
                    // the all-fp32 path, whose workspace is a prefix of this one
         return casmtr_dual_softmax_fwd(feat0, feat1, mask0, mask1, temperature, recip, thr, border_rm, valid_hw, h0c, w0c, h1c, w1c, want_conf,
                                        sim_ws, stats_ws, next_idx01, next_conf01, next_idx10, next_conf10, b_ids, i_ids, j_ids, mconf, n_matches,
