@@ -687,32 +687,37 @@ __global__ __launch_bounds__(256) void ds_xclaim_kernel(DsWs w, int B, int L, in
 }
 
 // (3) exact (max, sum exp) partials of the listed lines over one 128-wide block, in ds_tile_epilogue<RECIP, false>'s order.
-// Workgroup = (pair, side, group of up to 32 listed lines, four consecutive blocks); its four waves take one block each and ALL the
-// group's lines: the lines' own rows sit once in LDS (pre-scaled, read as broadcasts), the block's 128 rows of the OTHER side pass
-// through the wave's transposition slab once (32 channels at a time, coalesced 128-byte rows, the next step's rows in flight), and
-// the wave extends 2 x 32 chains -- lane <-> entry (two halves of 64), c ascending across the chunks = the oracle's chain.  With ~22
-// lines per list the whole call is ONE round of ~340 workgroups whose inner loops are long uninterrupted FMA streams.
+// The logits are a small exact GEMM -- up to 32 listed lines x the block's 128 entries x C channels -- and run where the exact path
+// runs its GEMM: v_mfma_f32_32x32x2_f32, whose k-sequence IS the oracle's c-ascending fmaf chain (products commute, so it does not
+// matter on which side the line is).  Workgroup = (pair, side, group of up to 32 listed lines, four consecutive blocks); the lines'
+// own rows sit once in LDS, pre-scaled (pitch 257 floats: operand A = a[line lane % 32][2 m + lane / 32] is a conflict-free
+// ds_read2_b32 per two MFMAs); every wave takes one block: its 128 rows of the OTHER side pass 32 rows x 32 channels at a time through
+// the wave's transposition slab (coalesced 128-byte rows, two steps in flight), lane (j, hi) picks channels 2 m + hi of row j as
+// operand B.  32 steps x 16 MFMAs per unit = 16 us on one SIMD; ~1360 units per call.
 // (History, all measured in the bench step with ~350 listed lines: a lane-per-row walk per line 1.4 ms (texture-address bound); a wave
-// per line 0.7 ms (each pass re-reads the other side's 11 MB at a 1 KB stride); a wave per 8 lines, with and without a shared slab,
-// 0.16-0.24 ms: two or more rounds of short units whose per-step latency -- transposition, barrier, a broadcast read in front of every
-// four FMAs -- was never covered; spilled accumulators and a scheduler that hoisted the next transposition above the current chains
-// cost another 2x on the way.)  Then four lanes per line replay what one LANE of the tile kernel reduces, from the logits parked in LDS:
+// per line 0.7 ms (each pass re-reads the other side's 11 MB at a 1 KB stride); VALU chains, 8 or 32 lines per pass, 0.15-0.24 ms:
+// one broadcast ds_read_b128 in front of every four FMAs, accumulators that spilled, v_pk_fma_f32 that hipcc packs two chains into.)
+// Then four lanes per line replay what one LANE of the tile kernel reduces, from the logits parked in LDS, 8 lines at a time:
 //   rows:    wave wc = half of the tile covers columns 64 wc .. 64 wc + 63; its lane (hi, row) scans columns 32 hi + c, c ascending;
 //   columns: wave wr = half covers rows 64 wr .. 64 wr + 63; its lane (hi, col) scans rows 32 ti + (r & 3) + 8 (r >> 2) + 4 hi in
 //            (ti, r) order --
 // the lane pair (hi = 0, 1) shares its maximum and adds its sums, and the two halves combine as the tile kernel's step 4 does.
-#define DS_XL_GB 32   // lines per workgroup unit
+#define DS_XL_GB 32    // lines per workgroup unit = rows of the MFMA tile
+#define DS_XL_SLP 257  // pitch of an own row in LDS (floats)
 template <bool RECIP>
-__global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+__global__ __launch_bounds__(256, 2) void ds_xstats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                         const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
                                                         int B, int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT,
                                                         int NJB, int NIB) {
-    constexpr int GB = DS_XL_GB;
+    constexpr int GB = DS_XL_GB, SLP = DS_XL_SLP, SLABF = 32 * 36;   // slab: 32 rows x 32 channels, rows padded to 36 floats
+    static_assert(8 * 128 <= SLABF, "the logits of 8 lines alias the slab");
     extern __shared__ __attribute__((aligned(16))) float xs_smem[];
-    float* sl = xs_smem;                                   // [GB][256] the lines' own rows, scaled by 1 / sqrt(C) (C <= 256); shared by the 4 waves
+    float* sl = xs_smem;                                   // [GB][SLP] the lines' own rows, scaled by 1 / sqrt(C) (C <= 256); shared by the 4 waves
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* slab = xs_smem + GB * 256 + wave * CASMTR_SLAB_FLOATS;   // wave-private transposition slab; later the logits of 8 lines
+    static_assert((GB * SLP) % 4 == 0, "slab alignment");
+    float* slab = xs_smem + GB * SLP + wave * SLABF;       // wave-private transposition slab; later the logits of 8 lines
+    const int hi = lane >> 5, jl = lane & 31;
     long long g = blockIdx.x;
     long long base = 0;
     // list lengths: one load per 64 lists (lane <-> list): the counters were written by device-scope atomics, every first read misses
@@ -743,103 +748,82 @@ __global__ __launch_bounds__(256) void ds_xstats_kernel(const float* __restrict_
                     rv[k] = lane * 4 < C ? *reinterpret_cast<const f32x4*>(pown + (size_t)self * C + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    *reinterpret_cast<f32x4*>(sl + (8 * wave + k) * 256 + lane * 4) =
-                        (f32x4){div_scalar<RECIP>(rv[k].x, sqrtC, inv_sqrtC), div_scalar<RECIP>(rv[k].y, sqrtC, inv_sqrtC),
-                                div_scalar<RECIP>(rv[k].z, sqrtC, inv_sqrtC), div_scalar<RECIP>(rv[k].w, sqrtC, inv_sqrtC)};
+                for (int k = 0; k < 8; ++k) {
+                    float* d = sl + (8 * wave + k) * SLP + lane * 4;
+                    d[0] = div_scalar<RECIP>(rv[k].x, sqrtC, inv_sqrtC); d[1] = div_scalar<RECIP>(rv[k].y, sqrtC, inv_sqrtC);
+                    d[2] = div_scalar<RECIP>(rv[k].z, sqrtC, inv_sqrtC); d[3] = div_scalar<RECIP>(rv[k].w, sqrtC, inv_sqrtC);
+                }
             }
             const bool selfmask = mown && mown[mine] == 0;   // lane k: line k of the group is a padded row / column
             __syncthreads();
             if (live) {
-                float acc[2][GB];
+                f32x16 acc[4];                               // sub-tile sub: D[line][32 sub + j]
 #pragma unroll
-                for (int half = 0; half < 2; ++half)
+                for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                    for (int k = 0; k < GB; ++k) acc[half][k] = 0.f;
-                auto load_rows = [&](int step, f32x4 (&v)[8]) {
-                    const int ks = step >> 1, o0 = t * 128 + (step & 1) * 64;
+                    for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
+                // step = 4 ks + sub: rows 32 sub .. 32 sub + 31 of the block, channels 32 ks .. 32 ks + 31 (4 loads per lane)
+                auto load_rows = [&](int ks, int sub, f32x4 (&v)[4]) {
+                    const int o0 = t * 128 + sub * 32;
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj)
+                    for (int jj = 0; jj < 4; ++jj)
                         v[jj] = *reinterpret_cast<const f32x4*>(pother + (size_t)min(o0 + 8 * jj + (lane >> 3), M - 1) * C + ks * 32 + (lane & 7) * 4);
                 };
-                f32x4 v[8];
-                load_rows(0, v);
-                for (int ks = 0; ks < C / 32; ++ks)
+                f32x4 v0[4], v1[4];                          // steps s + 1 and s + 2 in flight while step s runs
+                load_rows(0, 0, v0);
+                load_rows(0, 1, v1);
+                const float* arow = sl + jl * SLP + hi;      // operand A: a[line lane % 32][2 m + lane / 32]
+                const int nks = C / 32;
+                for (int ks = 0; ks < nks; ++ks)
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {   // compile-time half: acc[step & 1][k] would make the accumulators a scratch array
-                    const int step = 2 * ks + hf;
+                for (int sub = 0; sub < 4; ++sub) {
+                    f32x4 (&v)[4] = (sub & 1) ? v1 : v0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(slab + (8 * jj + (lane >> 3)) * 36 + (lane & 7) * 4) = v[jj];
+                    wave_lds_fence_();
                     f32x4 x[8];
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) *reinterpret_cast<f32x4*>(slab + (8 * jj + (lane >> 3)) * 36 + (lane & 7) * 4) = v[jj];
+                    for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const f32x4*>(slab + jl * 36 + i * 4);
                     wave_lds_fence_();
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const f32x4*>(slab + lane * 36 + i * 4);
-                    wave_lds_fence_();
-                    if (step + 1 < 2 * (C / 32)) load_rows(step + 1, v);   // ~2 us away (HBM / Infinity Cache at a 1 KB stride); this step runs longer
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        x[i].x = div_scalar<RECIP>(x[i].x, sqrtC, inv_sqrtC); x[i].y = div_scalar<RECIP>(x[i].y, sqrtC, inv_sqrtC);
-                        x[i].z = div_scalar<RECIP>(x[i].z, sqrtC, inv_sqrtC); x[i].w = div_scalar<RECIP>(x[i].w, sqrtC, inv_sqrtC);
+                    {   // refill this ring slot with step s + 2
+                        const int s2 = 4 * ks + sub + 2;
+                        if (s2 < 4 * nks) load_rows(s2 >> 2, s2 & 3, v);
                     }
-                    // lines in groups of 8 (a group beyond the list is skipped), channels outer / lines inner inside a group: the 8
-                    // broadcast reads of a channel quad are independent of each other and of the 8 chains they feed
 #pragma unroll
-                    for (int gq = 0; gq < GB / 8; ++gq) {
-                        if (8 * gq < ng) {
-                            // the broadcast reads of channel quad i + 1 are issued before the chains of quad i run (double-buffered by hand;
-                            // the fence keeps the scheduler from hoisting a whole step's reads: 256 live VGPRs, spills)
-                            f32x4 a4n[8];
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) a4n[k] = *reinterpret_cast<const f32x4*>(sl + (8 * gq + k) * 256 + ks * 32);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                f32x4 a4[8];
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) a4[k] = a4n[k];
-                                asm volatile("" ::: "memory");
-                                if (i < 7) {
-#pragma unroll
-                                    for (int k = 0; k < 8; ++k) a4n[k] = *reinterpret_cast<const f32x4*>(sl + (8 * gq + k) * 256 + ks * 32 + 4 * (i + 1));
-                                }
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {   // fmaf(a, b, acc) == fmaf(b, a, acc): the oracle's chain whichever side the line is on
-                                    // v_fmac_f32 by hand: hipcc SLP-packs the chains of two lines into v_pk_fma_f32 otherwise
-                                    float a_ = acc[hf][8 * gq + k];
-                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].x), "v"(x[i].x));
-                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].y), "v"(x[i].y));
-                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].z), "v"(x[i].z));
-                                    asm("v_fmac_f32 %0, %1, %2" : "+v"(a_) : "v"(a4[k].w), "v"(x[i].w));
-                                    acc[hf][8 * gq + k] = a_;
-                                }
-                            }
-                        }
+                    for (int q = 0; q < 8; ++q) {            // channels 4 q .. 4 q + 3 of the chunk: MFMAs m = 2 q, 2 q + 1 (k = 2 m + hi)
+                        const float a0 = arow[ks * 32 + 4 * q], a1 = arow[ks * 32 + 4 * q + 2];                 // one ds_read2_b32
+                        const float b0 = div_scalar<RECIP>(hi ? x[q].y : x[q].x, sqrtC, inv_sqrtC);
+                        const float b1 = div_scalar<RECIP>(hi ? x[q].w : x[q].z, sqrtC, inv_sqrtC);
+                        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[sub], 0, 0, 0);
+                        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[sub], 0, 0, 0);
                     }
-                    // the chains of this step finish HERE, before the next step's slab writes (which wait for the prefetched rows)
-                    asm volatile("" : "+v"(acc[hf][0]), "+v"(acc[hf][8]), "+v"(acc[hf][16]), "+v"(acc[hf][24]) :: "memory");
+                    asm volatile("" : "+v"(acc[sub]) :: "memory");   // the step's MFMAs stay in front of the next step's slab writes
                 }
-                // ---- the tile kernel's reduction, 8 lines at a time: logits -> slab (as [8][128]), lanes 4 k + q replay line k
+                // ---- the tile kernel's reduction, 8 lines at a time.  D layout: lane (j, hi), register r -> line (r & 3) + 8 (r >> 2) + 4 hi:
+                // the lines of group gq are registers 4 gq .. 4 gq + 3 -> line-in-group rr + 4 hi; logits -> slab as [8][128]
 #pragma unroll
                 for (int gq = 0; gq < GB / 8; ++gq) {
                     if (8 * gq < ng) {
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int o = t * 128 + half * 64 + lane;
+                        for (int sub = 0; sub < 4; ++sub) {
+                            const int o = t * 128 + sub * 32 + jl;
                             const bool om = mother && o < M && mother[o] == 0;
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const int kl = rr + 4 * hi;     // line within the group
                                 float vv = -INFINITY;           // outside the matrix: never wins a max, adds exp(-inf) = 0
-                                const bool sm_ = __shfl((int)selfmask, 8 * gq + k) != 0;
-                                if (o < M) vv = (om || sm_) ? NEG_FILL : div_scalar<RECIP>(acc[half][8 * gq + k], T, invT);
-                                slab[k * 128 + half * 64 + lane] = vv;
+                                const bool sm_ = __shfl((int)selfmask, 8 * gq + kl) != 0;
+                                if (o < M) vv = (om || sm_) ? NEG_FILL : div_scalar<RECIP>(acc[sub][4 * gq + rr], T, invT);
+                                slab[kl * 128 + sub * 32 + jl] = vv;
                             }
                         }
                         wave_lds_fence_();
-                        const int k = lane >> 2, q = lane & 3, half = q >> 1, hi = q & 1;
+                        const int k = lane >> 2, q = lane & 3, half = q >> 1, hh = q & 1;
                         const float* xk = slab + (k < 8 ? k : 0) * 128;
                         float xe[32];
 #pragma unroll
                         for (int e = 0; e < 32; ++e) {
-                            const int local = col ? ((e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hi) : (32 * hi + e);
+                            const int local = col ? ((e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hh) : (32 * hh + e);
                             xe[e] = xk[half * 64 + local];
                         }
                         float m = -INFINITY;
@@ -1022,8 +1006,8 @@ int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mas
     hipLaunchKernelGGL(ds_xnear_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w, L, B * L, thr, kthr);
     hipLaunchKernelGGL(ds_xclaim_kernel, dim3(DS_X_CAP / 256), dim3(256), 0, s, w, B, L, S);
     CASMTR_CHECK_LAUNCH();
-    // (pair, side, group of 32 listed lines, four blocks) units, one workgroup each, grid-strided: one round for the usual ~340 units
-    const size_t xs_lds = sizeof(float) * (DS_XL_GB * 256 + 4 * CASMTR_SLAB_FLOATS);
+    // (pair, side, group of 32 listed lines, four blocks) units, one workgroup each, grid-strided: one round for the usual ~350 units
+    const size_t xs_lds = sizeof(float) * (DS_XL_GB * DS_XL_SLP + 4 * 32 * 36);
     if (recip) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_xstats_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_lds);
         hipLaunchKernelGGL(ds_xstats_kernel<true>, dim3(512), dim3(256), xs_lds, s, feat0, feat1, mask0, mask1, w, B, L, S, C, sqrtC, 1.0f / sqrtC,

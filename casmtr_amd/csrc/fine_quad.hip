@@ -391,32 +391,55 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     float pend_acc = 0.f, pend_sc = 0.f;
     int pend_b = 0, pend_l00 = 0, pend_idx = 0;
     bool have_pend = false;
+    // What only the stores of an item's results use -- five output pointers, L, HD, w0, top-k, the level weight -- lives in VGPRs
+    // (opaque copies: the compiler cannot tell that they are wave-uniform).  In SGPRs they pushed the EXACT instances over the 102
+    // scalar registers: ~107 v_readlane reloads + ~109 hazard s_nop per item in the middle level's loop (a seventh of its instructions).
+    // (Only where the scalar file overflows and vector registers are to spare: the 128-candidate instances with top-k, 3 waves per SIMD.
+    //  The 64-candidate ones run at 4 waves per SIMD = 128 VGPRs and would spill vector registers instead.)
+    constexpr bool IN_VGPR = EXACT && NPASS == 2;
+    auto vg = [](auto x) { if constexpr (IN_VGPR) asm volatile("" : "+v"(x)); return x; };
+    auto vgp = [&](auto* ptr) {
+        if constexpr (!IN_VGPR) return ptr;
+        else {
+            unsigned lo = (unsigned)(unsigned long long)ptr, hi2 = (unsigned)((unsigned long long)ptr >> 32);
+            asm volatile("" : "+v"(lo), "+v"(hi2));
+            return reinterpret_cast<decltype(ptr)>(((unsigned long long)hi2 << 32) | lo);
+        }
+    };
+    float* const o_message = vgp(a.message);
+    float* const o_acc = vgp(a.acc_out);
+    int32_t* const o_tab = vgp(a.topk_tab);
+    float* const o_score = vgp(a.topk_score);
+    int64_t* const o_idx = vgp(a.topk_idx);
+    const int vL = vg(L), vHD = vg(HD), vw0 = vg(a.w0), vtopk = vg(a.topk), vH = vg(H), vh = vg(h);
+    const float vwl = vg(a.w_level);
     auto flush = [&]() {
         if (have_pend) {
             const int hi = lane >> 5;
             const float vA = hi ? pend[2] : pend[0], vB = hi ? pend[3] : pend[1];
-            const size_t o = ((size_t)pend_b * L + pend_l00 + hi * a.w0) * HD + h * 32 + (lane & 31);
-            if (a.message) { a.message[o] = vA; a.message[o + HD] = vB; }
+            const size_t o = ((size_t)pend_b * vL + pend_l00 + hi * vw0) * vHD + vh * 32 + (lane & 31);
+            if (a.message) { o_message[o] = vA; o_message[o + vHD] = vB; }
             if (a.acc_out) {   // separate multiply and add (:277-281)
-                const float rA = pend_acc + vA * a.w_level, rB = pend_acc + vB * a.w_level;
+                const float rA = pend_acc + vA * vwl, rB = pend_acc + vB * vwl;
                 if (a.xflags & 2) {
-                    __builtin_nontemporal_store(rA, a.acc_out + o);
-                    __builtin_nontemporal_store(rB, a.acc_out + o + HD);
+                    __builtin_nontemporal_store(rA, o_acc + o);
+                    __builtin_nontemporal_store(rB, o_acc + o + vHD);
                 } else if (a.xflags & 4) {
-                    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(a.acc_out + o), "v"(rA) : "memory");
-                    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(a.acc_out + o + HD), "v"(rB) : "memory");
+                    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(o_acc + o), "v"(rA) : "memory");
+                    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(o_acc + o + vHD), "v"(rB) : "memory");
                 } else {
-                    a.acc_out[o] = rA;
-                    a.acc_out[o + HD] = rB;
+                    o_acc[o] = rA;
+                    o_acc[o + vHD] = rB;
                 }
             }
             if constexpr (EXACT) {
                 const int f = lane >> 4, j = lane & 15, rank = (j & 1) * 8 + (j >> 1);
-                if (rank < a.topk) {
-                    const size_t lf = (size_t)pend_b * L + pend_l00 + (f >> 1) * a.w0 + (f & 1);
-                    if (a.topk_tab) a.topk_tab[(((size_t)pend_b * H + h) * L + (lf - (size_t)pend_b * L)) * a.topk + rank] = pend_idx;
-                    if (a.topk_idx) a.topk_idx[(lf * a.topk + rank) * H + h] = pend_idx;
-                    if (a.topk_score) a.topk_score[(lf * a.topk + rank) * H + h] = pend_sc;
+                if (rank < vtopk) {
+                    const size_t lt = (size_t)pend_l00 + (f >> 1) * vw0 + (f & 1);          // token within the pair
+                    const size_t lf = (size_t)pend_b * vL + lt;
+                    if (a.topk_tab) o_tab[(((size_t)pend_b * vH + vh) * vL + lt) * vtopk + rank] = pend_idx;
+                    if (a.topk_idx) o_idx[(lf * vtopk + rank) * vH + vh] = pend_idx;
+                    if (a.topk_score) o_score[(lf * vtopk + rank) * vH + vh] = pend_sc;
                 }
             }
         }
