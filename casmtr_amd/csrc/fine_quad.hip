@@ -376,6 +376,11 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    // (Round 5, measured and removed: "slice warming".  A wave's first item of a new pair finds that pair's K / V slice cold in the L2 and
+    //  pays its K and its V round trip in sequence; with one slice for all pairs the finest level takes 169 instead of 191-204 us
+    //  (tools/fq_samepair.py, CASMTR_FQ_FLAGS=8).  Requesting the V rows of such an item together with its K rows -- the same DMA
+    //  instructions pointed at a 1 KB sink in LDS -- made the step SLOWER: finest level 2.29 -> 2.38 ms, middle level 1.30 -> 1.42 ms per
+    //  step in alternating runs on one box.  The extra 8-16 instructions sit in front of the K rows in the in-order return queue.)
 
     Item it_cur{}, it_nx{};
     take(it_cur);

@@ -18,9 +18,10 @@ Lq = Sp = (side // 2) ** 2
 prev = torch.stack([torch.argsort(torch.rand(B, Lq, Sp, generator=g, device="cuda"), dim=-1)[..., :Kp] for _ in range(H)], -1).contiguous()
 acc = rn(B, Lq, C)
 qq, kq, vq, tab = ops.tokens_to_quads(q, *hw), ops.tokens_to_quads(k, *hw), ops.tokens_to_quads(v, *hw), ops.topk_idx_to_tab(prev)
+LABEL = {"8": "one slice for all pairs", "0": "as shipped"}
 for flags in ("0", "8"):
     os.environ["CASMTR_FQ_FLAGS"] = flags
-    for wpx in (256, 320, 384, 448, 512):
+    for wpx in (256, 320, 384):
         os.environ["CASMTR_FQ_WAVES_PER_XCD"] = str(wpx)
         for _ in range(3):
             ops.qta_fine_level_quad(qq, kq, vq, tab, hw, hw, H, 0, w_level=0.3, acc_in=acc, want_message=False, want_topk=False)
@@ -30,4 +31,4 @@ for flags in ("0", "8"):
             ops.qta_fine_level_quad(qq, kq, vq, tab, hw, hw, H, 0, w_level=0.3, acc_in=acc, want_message=False, want_topk=False)
         e1.record()
         torch.cuda.synchronize()
-        print(f"flags {flags} ({'one slice for all pairs' if flags == '8' else 'as shipped'}): waves per XCD {wpx}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch", flush=True)
+        print(f"flags {flags} ({LABEL[flags]}): waves per XCD {wpx}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch", flush=True)
