@@ -3,7 +3,7 @@
 //
 // The round-1 path (coarse_logits / coarse_row / coarse_av, qta_fused.hip) moves a [B,H,L,S_pad] workspace through the memory system
 // three times and spends ~800 VALU instructions per row on the selection (two 64-lane bitonic sorts, exact expf + division per
-// element); the first fused attempt (coarse_fused.hip) kept a [16][S] tile in LDS and paid for it with strided operand loads and one
+// element); the first fused attempt (round 2, pruned in round 5) kept a [16][S] tile in LDS and paid for it with strided operand loads and one
 // row per wave at a time.  Here a workgroup owns 16 query rows of one (pair, head); wave w owns rows 4w .. 4w+3 and never shares them:
 //   QK^T   lane <-> key: v_mfma_f32_4x4x1 with A = q[row l%4][d] and B = this lane's key row element d gives every lane the 4 rows'
 //          logits of ITS key -- for key block e (64 keys) that is x[e][0..3], i.e. after the pass over all blocks a wave holds 4 whole

@@ -24,11 +24,6 @@ int casmtr_qta_fine_level_dma(const float* q, const float* key, const float* val
                               float w_level, const float* acc_in, float* message, float* acc_out, float* topk_score,
                               int64_t* topk_idx, int B, int h0, int w0, int h1, int w1, int H, int Kp, hipStream_t s);
 
-// fine_vreg.hip
-int casmtr_qta_fine_level_vreg(const float* q, const float* key, const float* value, const int64_t* prev_idx, float temp, int topk,
-                               float w_level, const float* acc_in, float* message, float* acc_out, float* topk_score,
-                               int64_t* topk_idx, int B, int h0, int w0, int h1, int w1, int H, int Kp, hipStream_t s);
-
 // =================================================================================================== layout
 // [B,C,HW] -> [B,HW,C] for up to 9 tensors in one launch (a QTAttB call converts 3 pyramids x q,k,v).
 // 64x64 tile through LDS; 16-byte global accesses on both sides (pixels contiguous on the way in, channels on the way out).
@@ -437,20 +432,15 @@ extern "C" int casmtr_qta_fine_level_fwd(const float* q, const float* key, const
                                          int h1, int w1, int H, int D, int Kp, casmtr_stream_t stream) {
     if (D != 32 || (h0 & 1) || (w0 & 1) || (h1 & 1) || (w1 & 1) || topk > 4 * Kp) return CASMTR_ERR_UNSUPPORTED;
     if (B <= 0 || h0 <= 0 || w0 <= 0) return 0;
-    // Three kernels, identical results.  Default for 4*Kp <= 64 (the finest level of every shipped config): the persistent
+    // Two kernels, identical results.  Default for 4*Kp <= 64 (the finest level of every shipped config): the persistent
     // wave-per-(quad, head) LDS-DMA + MFMA kernel (fine_dma.hip; 0.29 ms per launch at 104x104, K = 64, B = 8 against 0.335 for
     // the round-1 kernel); the round-1 workgroup-per-quad kernel below for longer lists (K = 128 with top-16: 0.21 ms against
-    // 0.25 -- the iterated top-k dominates and four waves share it).  fine_vreg.hip (values in registers instead of LDS, 12
-    // instead of 8 waves per CU) measured 0.285 against 0.291 ms and nothing in the whole step: kept selectable, not default.
-    // CASMTR_FINE_KERNEL=vreg | dma | quad forces one of them where the shape allows (read per call: tests switch it).
+    // 0.25 -- the iterated top-k dominates and four waves share it).  (A third one, values in registers instead of LDS at 12 instead
+    // of 8 waves per CU, measured 0.285 against 0.291 ms and nothing in the whole step; pruned in round 5)
+    // CASMTR_FINE_KERNEL=dma | quad forces one of them where the shape allows (read per call: tests switch it).
     {
         const char* ev = getenv("CASMTR_FINE_KERNEL");
-        const bool force_dma = ev && !strcmp(ev, "dma"), force_quad = ev && !strcmp(ev, "quad"), force_vreg = ev && !strcmp(ev, "vreg");
-        if (force_vreg) {
-            const int r = casmtr_qta_fine_level_vreg(q, key, value, prev_idx, temp, topk, w_level, acc_in, message, acc_out, topk_score,
-                                                     topk_idx, B, h0, w0, h1, w1, H, Kp, (hipStream_t)stream);
-            if (r != CASMTR_ERR_UNSUPPORTED) return r;
-        }
+        const bool force_dma = ev && !strcmp(ev, "dma"), force_quad = ev && !strcmp(ev, "quad");
         if (force_dma || (!force_quad && 4 * Kp <= 64)) {
             const int r = casmtr_qta_fine_level_dma(q, key, value, prev_idx, temp, topk, w_level, acc_in, message, acc_out, topk_score,
                                                     topk_idx, B, h0, w0, h1, w1, H, Kp, (hipStream_t)stream);
@@ -727,21 +717,18 @@ __global__ __launch_bounds__(256) void coarse_av_kernel(const float* __restrict_
     }
 }
 
-// coarse_fused.hip / coarse_tile.hip
-int casmtr_qta_coarse_level_fused(const float* q, const float* k, const float* v, float temp, int topk, float w_level, float* message,
-                                  float* acc_out, float* topk_score, int64_t* topk_idx, int B, int L, int S, int H, hipStream_t s);
+// coarse_tile.hip
 int casmtr_qta_coarse_level_tile(const float* q, const float* k, const float* v, float temp, int topk, float w_level, float* message,
                                  float* acc_out, float* topk_score, int64_t* topk_idx, int32_t* topk_tab, int B, int L, int S, int H,
                                  hipStream_t s);
 
-// Three implementations, identical indices.  Default (round 4): the register-tile kernel (coarse_tile.hip: logits born in the
+// Two implementations, identical indices.  Default (round 4): the register-tile kernel (coarse_tile.hip: logits born in the
 // selection's layout, no workspace; S <= 1024, topk <= 60).  CASMTR_COARSE_KERNEL=three selects the round-1 three-kernel path below
-// (also the fallback for shapes outside the tile kernel), =fused the round-2 LDS-tile kernel (coarse_fused.hip).  Read per call.
-// Measured at 26x26, H = 8, B = 8: three kernels 143-153 us per call, fused 197-206 us (see DESIGN.md for the tile kernel).
-enum { COARSE_TILE = 0, COARSE_THREE = 1, COARSE_FUSED = 2 };
+// (also the fallback for shapes outside the tile kernel).  Read per call.  (The round-2 LDS-tile kernel, 197-206 us per call against
+// 143-153 for the three kernels and 104 for the tile kernel at 26x26, H = 8, B = 8, was pruned in round 5.)
+enum { COARSE_TILE = 0, COARSE_THREE = 1 };
 static int coarse_mode(int S, int topk) {
     const char* ev = getenv("CASMTR_COARSE_KERNEL");
-    if (ev && !strcmp(ev, "fused") && S <= 1024) return COARSE_FUSED;
     if (ev && !strcmp(ev, "three")) return COARSE_THREE;
     return (S <= 1024 && topk >= 1 && topk <= 60 && topk <= S) ? COARSE_TILE : COARSE_THREE;
 }
@@ -777,12 +764,7 @@ extern "C" int casmtr_qta_coarse_level_tab_fwd(const float* q, const float* k, c
         const int r = casmtr_qta_coarse_level_tile(q, k, v, temp, topk, w_level, message, acc_out, topk_score, topk_idx, topk_tab, B, L, S, H, s);
         if (r != CASMTR_ERR_UNSUPPORTED) return r;
     }
-    if (mode == COARSE_FUSED && topk_score && topk_idx) {
-        const int r = casmtr_qta_coarse_level_fused(q, k, v, temp, topk, w_level, message, acc_out, topk_score, topk_idx, B, L, S, H, s);
-        if (r == 0 && topk_tab) return casmtr_topk_idx_to_tab(topk_idx, topk_tab, B, L, topk, H, stream);
-        if (r != CASMTR_ERR_UNSUPPORTED) return r;
-    }
-    // casmtr_qta_coarse_level_ws_floats_k() promised a 1-float workspace for the tile / fused modes: if such a kernel still declines
+    // casmtr_qta_coarse_level_ws_floats_k() promised a 1-float workspace for the tile mode: if that kernel still declines
     // the shape (e.g. S * H * 128 >= 2^31 in the tile kernel) the three-kernel path below must NOT run on that dummy workspace
     if (mode != COARSE_THREE) return CASMTR_ERR_UNSUPPORTED;
     if (!logits_ws || !topk_score || !topk_idx) return CASMTR_ERR_UNSUPPORTED;   // the three-kernel path needs its workspace and writes both lists

@@ -158,7 +158,7 @@ class QTAttB(nn.Module):
 
     def _quad_major_ok(self, hw_q, hw_k):
         """The finer levels run on quad-major operands (csrc/fine_quad.hip) whenever their shapes allow it; CASMTR_FINE_KERNEL =
-        dma | quad | vreg keeps the round-2 token-major kernels (tests compare the two)."""
+        dma | quad keeps the token-major kernels (tests compare the two)."""
         import os
         if os.environ.get("CASMTR_FINE_KERNEL", "qm") != "qm" or len(hw_q) < 2:
             return False

@@ -158,16 +158,6 @@ def test_compat_aliases_block_module():
     assert tuple(m.q_proj.weight.shape) == (64, 64, 1, 1)
 
 
-def test_fine_vreg_isa_guard():
-    """fine_vreg.hip loads its value rows by inline asm and validates them with a hand-written s_waitcnt: the compiled code must
-    not read, copy or spill those registers before the wait (tools/check_vreg_isa.py)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_vreg_isa.py")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
 def test_quad_kernels_isa_guard():
     """fine_quad.hip / cascade_quad.hip issue their LDS-DMA chunks from inline asm that writes M0 and is waited for with hand-counted
     vmcnt: the compiled kernels must not touch M0 elsewhere and must not spill (tools/check_quad_isa.py)."""

@@ -130,7 +130,7 @@ def test_quad_major_layout_passes(ops):
     assert np.array_equal(N(ops.topk_idx_to_tab(T(idx))), idx.transpose(0, 3, 1, 2).astype(np.int32))
 
 
-@pytest.mark.parametrize("kernel", ["qm", "vreg", "dma", "quad"])
+@pytest.mark.parametrize("kernel", ["qm", "dma", "quad"])
 @pytest.mark.parametrize("name", list(CASES["qtattb"]))
 def test_qtattb_levels(ops, monkeypatch, name, kernel):
     """coarse + fine level kernels chained exactly like QTAttB.forward; indices bit-exact vs oracle AND vs the reference."""
@@ -381,9 +381,9 @@ def test_fine_level_wide_candidate_lists(ops, H, Kp, topk):
 
 @pytest.mark.parametrize("H,Kp,topk,with_acc", [(8, 16, 8, True), (8, 32, 16, True), (8, 16, 0, True), (4, 32, 16, False), (2, 9, 5, True),
                                                  (1, 16, 4, True), (4, 5, 20, True), (8, 1, 4, True), (2, 13, 0, False)])
-@pytest.mark.parametrize("kernel", ["qm", "vreg", "dma"])
+@pytest.mark.parametrize("kernel", ["qm", "dma"])
 def test_fine_level_dma_kernel_shapes(ops, monkeypatch, kernel, H, Kp, topk, with_acc):
-    """fine_level_vreg_kernel (K = 4*Kp <= 64; longer lists fall through) and fine_level_dma_kernel (K <= 128): every head count /
+    """fine_level_dma_kernel (K <= 128) against the quad-major kernel: every head count /
     XCD split, ragged candidate counts, top-k == K, no top-k (finest level), no incoming accumulator, query grid != key grid,
     several pairs -- top-k bit-exact, messages within tolerance"""
     monkeypatch.setenv("CASMTR_FINE_KERNEL", kernel)
@@ -479,7 +479,7 @@ def test_empty_batch_and_limits(ops):
         ops.window_match(z(1, 16, 64), z(1, 400, 64), torch.zeros((1, 16, 144), device=DEV, dtype=torch.int64))
 
 
-@pytest.mark.parametrize("kernel", ["tile", "three", "fused"])
+@pytest.mark.parametrize("kernel", ["tile", "three"])
 @pytest.mark.parametrize("kind", ["random", "all_equal", "one_lane_heavy", "many_ties", "few_valid", "wide_range", "indoor", "ragged", "tiny", "widest", "one_head"])
 def test_coarse_topk_paths(ops, monkeypatch, kind, kernel):
     """coarse-level top-k: the sorted fast path (<= 64 survivors of the lane-maxima threshold; in the tile kernel the exact 32-bit

@@ -29,7 +29,7 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for kern, flagset in (("tile", (0, 256, 512, 768)), ("three", (0,)), ("fused", (0, 1, 2, 4, 6))):
+for kern, flagset in (("tile", (0, 256, 512, 768)), ("three", (0,))):
     os.environ["CASMTR_COARSE_KERNEL"] = kern
     for flags in flagset:
         _lib.lib().casmtr_debug_set(flags)

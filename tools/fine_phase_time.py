@@ -35,7 +35,7 @@ for name, side, Kp, topk in (("L1 52x52 K=128 top16", 52, 32, 16), ("L0 104x104 
     prev = torch.stack([torch.argsort(torch.rand(B, Lq, Sp, generator=g, device="cuda"), dim=-1)[..., :Kp] for _ in range(H)], -1).contiguous()
     acc = rn(B, Lq, C)
     lv[name] = (q, k, v, prev, side, topk, acc)
-for kern in ("vreg", "dma", "quad"):
+for kern in ("dma", "quad"):
     os.environ["CASMTR_FINE_KERNEL"] = kern
     for flags in ((0, 1, 2, 3) if kern == "dma" else (0,)):  # the phase switches exist in the dma kernel only
         _lib.lib().casmtr_debug_set(flags)
