@@ -1,25 +1,34 @@
 // Finest QTAttB level with LOADER-WAVE SPECIALISATION (round 5): the same items, layout and arithmetic as fine_quad_kernel<1, false, true>
 // (cuda_imp/QuadTreeAttention/QuadtreeAttention/modules/quadtree_attention.py:180-229 with lists of exactly 64 candidates and no top-k:
-// the finest level of every shipped config), but the waves of a workgroup take two roles.
+// the finest level of every shipped config) -- results bit-equal to that kernel's -- but the waves of a workgroup take two roles.
 //
 // Why.  In fine_quad.hip every wave issues its own LDS-DMA gathers and then works through an item's serial instruction stream (LDS reads,
-// 64 dependent-ish MFMAs, softmax through LDS); while it does, it has nothing in flight.  Counters and probes: on
-// average 8 KB of reads are in flight per CU out of the 80 KB ten waves could have; the gather alone runs at 105-127 us per launch
-// (the texture-address path's ~19 cycles per 1 KB instruction), the kernel at 190-204; and more waves are not available because the
-// eight (pair, head) slices an XCD walks stop fitting its L2 when more than ~3 MB of gathers are in flight.  So: keep the number of
-// waves that GATHER small and their queue always full, and let the others only compute.
+// 64 MFMAs, softmax through LDS); while it does, it has nothing in flight.  Counters and probes: on average 8 KB of
+// reads are in flight per CU out of the 80 KB ten waves could have; the gather alone runs at 105-127 us per launch (the texture-address
+// path's ~19 cycles per 1 KB instruction), the kernel at 190-204; a consumer that never waits needs ~2800 cycles per item.  More waves
+// are not available (the eight (pair, head) slices an XCD walks stop fitting its L2 when too many gathers queue up), so: few waves
+// that only GATHER, with their queue always full, and waves that only COMPUTE.
 //
-// Workgroup = 1 loader wave + 3 consumer waves, 3 workgroups per CU.  Per consumer: a ring of three 4 KB chunk slots, the probability
-// buffer, a double-buffered 1 KB staging area (queries, parent list, final[parent] row) and three counters in LDS:
-//   landed  (loader -> consumer)  chunks of this consumer whose DMA has landed
-//   freed   (consumer -> loader)  chunks it has finished reading
-//   sfreed  (consumer -> loader)  items whose staging area it no longer needs
-// An item is four chunks, K0 K1 V0 V1 (8 parents x 512 B each), chunk n in slot n % 3.  The loader walks its three consumers round
-// robin: stages the next item's front end (one 16-byte-wide DMA instruction), turns the staged parent list into DMA offsets, issues a
-// chunk whenever its slot is free, and retires its DMA groups IN ORDER (vmcnt counts them in order): a FIFO of (owner, kind) codes in a
-// 64-bit register tells whose counter the oldest group bumps.  The consumer polls `landed`, reads, bumps `freed`, computes; its global
-// stores are ordinary compiler-visible stores (its own vmcnt has nothing hand-counted in it).
+// Workgroup = 1 loader wave + 2 consumer waves; 4 workgroups per CU (12 waves, 8 of them consumers).  Per consumer in LDS: a K ring
+// (64 rows x 128 B = the candidate rows of one item), a V ring of the same size, the probability buffer, a double-buffered 704-byte
+// staging area (queries 512 B, parent list 64 B, final[parent] row 128 B) and six 4-byte counters.
+//
+// Hand-shakes without a single blocking wait in the loader: the loader never waits for its own DMAs.  Behind the eight gather
+// instructions of a K (or V) set, and behind a staging instruction, it issues ONE more LDS-DMA instruction with a single active lane
+// that copies a word known to be >= 0 (the first index of the item's own parent list: a line the staging instruction has just
+// fetched, different for every item -- a shared table of sequence numbers made one L2 line the hot spot of the whole chip) over the
+// consumer's `klanded` / `vlanded` / `slanded` stamp word, which holds -1.  A wave's vector-memory operations return in order (that
+// is what vmcnt counts), so when the stamp is >= 0 the rows are in LDS: the hardware publishes the landing.  The reader of a stamp
+// resets it to -1 before it frees the ring.  In the other direction the consumer bumps `kfreed` / `vfreed` / `sfreed` with plain LDS
+// stores once its reads have completed (lgkmcnt(0)).  The loader walks its two consumers round robin and issues whatever is allowed:
+//   staging of item s      : s <= (item being gathered) + 1, and sfreed >= s - 1 (the buffer's previous user is done with it)
+//   K rows of item i       : its staging stamp is set (the parent list is there) and kfreed >= i (the K ring has been read)
+//   V rows of item i       : after its K rows, and vfreed >= i
+// so the K rows of item i + 1 are on their way while item i is still in its softmax, its V rows while item i + 1 runs its K pass.
 // Every spin is bounded: a protocol error would end the kernel with wrong results and a raised flag, not hang the device.
+// (First version, commit fe1e2be: 1 loader + 3 consumers, three 4 KB slots each, landings published by the loader after an in-order
+// `s_waitcnt vmcnt` retire through a FIFO of group codes: 1.2 ms per launch, the loader wave executing ~7600 cycles of its own
+// bookkeeping per item served.)
 #include <stdio.h>
 #include <stdlib.h>
 #include "quad_common.hpp"
@@ -35,42 +44,42 @@ struct FineLwArgs {
     const float* acc_in;     // nullable [B,Lq0,H*32]
     float* message;          // nullable [B,L,H*32]
     float* acc_out;          // nullable [B,L,H*32]
+    const int* seq;          // A/B: nullable replicated table seq[r][k] = k + 1 (r < 256, k < 2048)
     int* err;                // nullable: set to 1 when a bounded spin ran out
-    unsigned long long* dbg; // nullable (CASMTR_LW_DEBUG): [0..3] consumer cycles waiting for K / V0 / V1 / total, [4] items; [5..7] loader: blocked in vmcnt, idle, total
+    unsigned long long* dbg; // nullable (CASMTR_LW_DEBUG): [0] consumer cycles waiting for K, [1] for V, [3] total, [4] items; [6] loader idle, [7] loader total
     float temp, w_level;
     int B, h0, w0, H, nquads, lq1;
 };
 
 #define LW_SPIN_MAX (1 << 22)
 
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {   // pins a wave-uniform address to an SGPR pair
+__device__ __forceinline__ const char* lw_uniform_ptr(const char* p) {   // pins a wave-uniform address to an SGPR pair
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
-// wait until at most n (wave-uniform, 0..63) vector-memory operations are outstanding: s_waitcnt takes an immediate
-__device__ __forceinline__ void vmwait_dyn(int n) {
-#define LW_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (n) {
-        LW_W(0) LW_W(1) LW_W(2) LW_W(3) LW_W(4) LW_W(5) LW_W(6) LW_W(7) LW_W(8) LW_W(9) LW_W(10) LW_W(11) LW_W(12) LW_W(13) LW_W(14) LW_W(15)
-        LW_W(16) LW_W(17) LW_W(18) LW_W(19) LW_W(20) LW_W(21) LW_W(22) LW_W(23) LW_W(24) LW_W(25) LW_W(26) LW_W(27) LW_W(28) LW_W(29) LW_W(30)
-        LW_W(31) LW_W(32) LW_W(33) LW_W(34) LW_W(35) LW_W(36) LW_W(37) LW_W(38) LW_W(39) LW_W(40) LW_W(41) LW_W(42) LW_W(43) LW_W(44) LW_W(45)
-        LW_W(46) LW_W(47) LW_W(48) LW_W(49) LW_W(50) LW_W(51) LW_W(52) LW_W(53) LW_W(54) LW_W(55) LW_W(56) LW_W(57) LW_W(58) LW_W(59) LW_W(60)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef LW_W
+// LDS words by byte address with explicit DS instructions (through a generic pointer the compiler emits FLAT loads, whose s_waitcnt
+// vmcnt(0) would make every poll wait for all of the wave's gathers)
+__device__ __forceinline__ int lw_ld(unsigned addr) {            // wave-uniform result
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lw_st(unsigned addr, int val) {   // one lane stores
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "v"(addr), "v"(val) : "memory");
 }
 
-__global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
-    constexpr int NC = 3;                  // consumers per workgroup
-    constexpr int SLOTS = 3;               // chunk slots per consumer
-    constexpr int DEPTH = 3;               // DMA groups the loader leaves in flight while it still has something to issue
-    constexpr int PST = 36, P_FLOATS = 8 * PST, KS = 68, STG = 256;
-    constexpr int CW = SLOTS * 1024 + P_FLOATS + 2 * STG;   // floats per consumer
+constexpr int LW_PST = 36, LW_P_FLOATS = 8 * LW_PST, LW_KS = 68;
+constexpr int LW_STG = 176;                         // floats per staging buffer: q 128 | parents 16 | final[parent] 32
+constexpr int LW_CW = 2 * 2048 + LW_P_FLOATS + 2 * LW_STG + 8;   // floats per consumer: K ring | V ring | P | staging x 2 | counters
+
+template <int NC, int WGS>   // consumers per workgroup; workgroups per CU
+__global__ __launch_bounds__(64 * (1 + NC), WGS) void fine_lw_kernel(const FineLwArgs a) {
+    constexpr int PST = LW_PST, P_FLOATS = LW_P_FLOATS, KS = LW_KS, STG = LW_STG, CW = LW_CW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    volatile int* ctrl = reinterpret_cast<volatile int*>(smem + NC * CW);   // [NC][4]: landed, freed, sfreed, -
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int H = a.H, HD = H * 32, Kp = 16;
@@ -80,113 +89,140 @@ __global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
     const int chunk = (Lq + G - 1) / G, cnt = min(chunk, Lq - g * chunk);
     const int total = (g < G && cnt > 0) ? a.B * cnt : 0;
     const int stride = (gridDim.x >> 3) * NC;
-    if (threadIdx.x < NC * 4) ctrl[threadIdx.x] = 0;
+    // words of consumer c (ints at the end of its LDS block): 0 klanded 1 vlanded 2, 3 slanded per staging buffer (stamps: -1 = not landed, written by DMA) | 4 kfreed 5 vfreed 6 sfreed (counters)
+    if (threadIdx.x < NC * 8) reinterpret_cast<volatile int*>(smem + (threadIdx.x >> 3) * CW + CW - 8)[threadIdx.x & 7] = (threadIdx.x & 7) < 4 ? -1 : 0;
     __syncthreads();
     auto items_of = [&](int t) { return t < total ? (total - t + stride - 1) / stride : 0; };
-    const size_t pair_pitch = (size_t)H * a.lq1 * 128;
-    const int un = lane & 7;
-    unsigned cK[4];   // DMA source offset inside a parent's 512-byte run, instruction j of a chunk (rows 8 j + lane / 8; see fine_quad.hip)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        cK[j] = (unsigned)(((lane >> 3) & 3) * 128 + ((un ^ (((j & 1) * 4 + (lane >> 4)) & 7)) * 16) + 3072 - j * 1024);
 
     if (wave == 0) {
         // ============================================================================================================ loader
+        const size_t pair_pitch = (size_t)H * a.lq1 * 128;
         const float* const k0 = a.key + (size_t)h * a.lq1 * 128 - 768;     // this head's slice of pair 0, 3072 bytes low
         const float* const v0 = a.value + (size_t)h * a.lq1 * 128 - 768;
-        // staging source per lane (one 16-byte unit each; fine_quad.hip): q 512 B | parents 64 B (4 units) | final[parent] 128 B
+        const int un = lane & 7;
+        unsigned cK[4];   // DMA source offset inside a parent's 512-byte run, instruction j of a 32-row half (rows 8 j + lane / 8; fine_quad.hip)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            cK[j] = (unsigned)(((lane >> 3) & 3) * 128 + ((un ^ (((j & 1) * 4 + (lane >> 4)) & 7)) * 16) + 3072 - j * 1024);
+        // staging source per lane (one 16-byte unit each, lanes 0..43): q 512 B | parents 64 B | final[parent] 128 B
         unsigned long long sbase;
         unsigned mulq, mula;
         {
-            const int u = lane < 48 ? lane : 47;
+            const int u = lane < 44 ? lane : 43;
             if (u < 32) {
                 const int r = u >> 3, pu = u & 7;
                 sbase = (unsigned long long)a.q + (unsigned)(r * 128 + ((pu ^ (r >> 1)) * 16));
                 mulq = 512u; mula = 0u;
-            } else if (u < 40 || !a.acc_in) {
-                sbase = (unsigned long long)a.parents + (unsigned)(min((u - 32) & 7, Kp / 4 - 1) * 16);
+            } else if (u < 36 || !a.acc_in) {
+                sbase = (unsigned long long)a.parents + (unsigned)(((u - 32) & 3) * 16);
                 mulq = (unsigned)(Kp * 4); mula = 0u;
             } else {
-                sbase = (unsigned long long)a.acc_in + (unsigned)(h * 128 + (u - 40) * 16);
+                sbase = (unsigned long long)a.acc_in + (unsigned)(h * 128 + (u - 36) * 16);
                 mulq = 0u; mula = (unsigned)(HD * 4);
             }
         }
         const int t0 = (blockIdx.x >> 3) * NC;
-        int T[NC], n[NC], s[NC], sl[NC];            // items, chunks issued, stagings issued, stagings landed
-        int scb[NC], scq[NC], ccb[NC], ccq[NC];     // cursors (pair, index in the XCD's chunk) of the next staging / of the current chunk item
-        unsigned ring_lds[NC], stg_lds[NC];
+        int T[NC], it[NC], s[NC], ph[NC];           // items; item being gathered; stagings issued; 0: offsets missing, 1: K next, 2: V next
+        int scb[NC], scq[NC], ccb[NC], ccq[NC];     // cursors (pair, index in the XCD's chunk) of the next staging / of the item being gathered
+        unsigned voff[NC][8];
+        unsigned kring[NC], stgl[NC], ctrl[NC];     // LDS byte addresses
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            T[c] = items_of(t0 + c); n[c] = 0; s[c] = 0; sl[c] = 0;
+            T[c] = items_of(t0 + c); it[c] = 0; s[c] = 0; ph[c] = 0;
             scb[c] = ccb[c] = (t0 + c) / max(cnt, 1); scq[c] = ccq[c] = (t0 + c) % max(cnt, 1);
-            ring_lds[c] = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem + c * CW));
-            stg_lds[c] = ring_lds[c] + (unsigned)((SLOTS * 1024 + P_FLOATS) * 4);
-        }
-        unsigned long long fifo = 0;     // 3 bits per outstanding DMA group, oldest in the low bits: owner (2 bits) | kind (bit 2: 1 = chunk)
-        int flen = 0, outst = 0;         // groups / instructions in flight
-        int spins = 0;
-        unsigned long long l_blk = 0, l_idle = 0;
-        const unsigned long long l_begin = __builtin_readcyclecounter();
-        const bool hh = lane >> 5;
-        for (;;) {
-            bool all_done = true;
-            bool issued = false;
-            // one snapshot of the consumers' counters per sweep (three LDS reads in flight together, one wait)
-            int freed[NC], sfreed[NC];
+            kring[c] = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem + c * CW));
+            stgl[c] = kring[c] + (unsigned)((4096 + P_FLOATS) * 4);
+            ctrl[c] = kring[c] + (unsigned)((CW - 8) * 4);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { freed[c] = ctrl[c * 4 + 1]; sfreed[c] = ctrl[c * 4 + 2]; }
+            for (int j = 0; j < 8; ++j) voff[c][j] = 0;
+        }
+        const bool hh = lane >> 5;
+        // one LDS-DMA instruction with ONE active lane: the first word of the item's parent list (an index >= 0) -> the stamp word at LDS byte
+        // address `dst`, which held -1; it lands behind everything this wave issued before
+        const unsigned long long pbase = (unsigned long long)a.parents;
+        const unsigned long long sq = (unsigned long long)a.seq + (unsigned long long)((blockIdx.x & 255) * 2048) * 4;
+        unsigned nstamp = 0;
+        const char* const seqb = lw_uniform_ptr(reinterpret_cast<const char*>(a.seq) + (size_t)((blockIdx.x & 255) * 2048) * 4);
+        const char* const parb = lw_uniform_ptr(reinterpret_cast<const char*>(a.parents));
+        auto stamp = [&](unsigned qd, unsigned dst) {
+            const unsigned off = a.seq ? ((nstamp++) & 2047u) * 4u : qd * (unsigned)(Kp * 4);
+            const char* const sb = a.seq ? seqb : parb;
+            const unsigned d = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
+            unsigned long long keep;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
+                         : "=&s"(keep) : "v"(off), "s"(sb), "s"(d) : "memory");
+        };
+        unsigned cqd[NC];   // (pair, head, quad) index of the item being gathered
+        int spins = 0, outst = 0;
+        unsigned long long l_idle = 0, l_blk = 0, l_iss = 0;
+        const unsigned long long l_begin = __builtin_readcyclecounter();
+        for (;;) {
+            bool all_done = true, issued = false;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                // ---- (a) the front end of item s[c]: at most one item ahead of the chunks, and its buffer (used by item s - 2) released
-                if (s[c] < T[c] && s[c] <= (n[c] >> 2) + 1 && (s[c] < 2 || sfreed[c] >= s[c] - 1)) {
+                const unsigned cc = ctrl[c];
+                // ---- the front end of item s: at most one item ahead of the gathers, its buffer (item s - 2's) released
+                if (s[c] < T[c] && s[c] <= it[c] + 1 && (s[c] < 2 || lw_ld(cc + 24u) >= s[c] - 1)) {
                     const unsigned quad = (unsigned)(g * chunk + scq[c]);
                     const unsigned qd = (unsigned)((scb[c] * H + h) * Lq) + quad, bq = (unsigned)(scb[c] * Lq) + quad;
                     const unsigned long long addr = sbase + (unsigned long long)qd * mulq + (unsigned long long)bq * mula;
-                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(stg_lds[c] + (unsigned)((s[c] & 1) * STG * 4)));
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(addr), "s"(dst) : "memory");
-                    fifo |= (unsigned long long)c << (3 * flen);
-                    ++flen; ++outst; ++s[c]; issued = true;
+                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(stgl[c] + (unsigned)((s[c] & 1) * STG * 4)));
+                    {
+                        unsigned long long keep;   // lanes 0..43
+                        asm volatile("s_mov_b64 %0, exec\n\ts_bfm_b64 exec, 44, 0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
+                                     : "=&s"(keep) : "v"(addr), "s"(dst) : "memory");
+                    }
+                    stamp(qd, ctrl[c] + 8u + (unsigned)((s[c] & 1) * 4));
+                    ++s[c];
+                    outst += 2; issued = true;
                     scq[c] += stride;
                     while (scq[c] >= cnt) { scq[c] -= cnt; ++scb[c]; }
                 }
-                // ---- (b) chunks n[c] ..: the item's parent list has landed and the slot (chunk n - 3's) has been read
-                for (int rep = 0; rep < SLOTS; ++rep) {
-                    const int i = n[c] >> 2;
-                    if (!(i < T[c] && sl[c] > i && n[c] - freed[c] < SLOTS)) break;
-                    const int kind = n[c] & 3, hc = kind & 1;       // K0 K1 V0 V1; half of the parent list
-                    const int* t2 = reinterpret_cast<const int*>(smem + c * CW + SLOTS * 1024 + P_FLOATS + (i & 1) * STG + 128);
-                    const int4 pa4 = *reinterpret_cast<const int4*>(t2 + 8 * hc), pb4 = *reinterpret_cast<const int4*>(t2 + 8 * hc + 4);
-                    const unsigned o0 = ((unsigned)(hh ? pa4.y : pa4.x) << 9) + cK[0], o1 = ((unsigned)(hh ? pa4.w : pa4.z) << 9) + cK[1];
-                    const unsigned o2 = ((unsigned)(hh ? pb4.y : pb4.x) << 9) + cK[2], o3 = ((unsigned)(hh ? pb4.w : pb4.z) << 9) + cK[3];
-                    const float* base = reinterpret_cast<const float*>(uniform_ptr(reinterpret_cast<const char*>(((kind & 2) ? v0 : k0) + (size_t)ccb[c] * pair_pitch)));
-                    glds_chunk(base, o0, o1, o2, o3, (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_lds[c] + (unsigned)((n[c] % SLOTS) * 4096))));
-                    fifo |= (unsigned long long)(c | 4) << (3 * flen);
-                    ++flen; outst += 4; ++n[c]; issued = true;
-                    if ((n[c] & 3) == 0) {
-                        ccq[c] += stride;
-                        while (ccq[c] >= cnt) { ccq[c] -= cnt; ++ccb[c]; }
+                if (it[c] < T[c]) {
+                    all_done = false;
+                    // ---- the parent list of item it -> the eight DMA offsets (K and V rows share them)
+                    if (ph[c] == 0 && lw_ld(cc + 8u + (unsigned)((it[c] & 1) * 4)) >= 0) {
+                        asm volatile("" ::: "memory");
+                        const int* t2 = reinterpret_cast<const int*>(smem + c * CW + 4096 + P_FLOATS + (it[c] & 1) * STG + 128);
+#pragma unroll
+                        for (int hc = 0; hc < 2; ++hc) {
+                            const int4 pa4 = *reinterpret_cast<const int4*>(t2 + 8 * hc), pb4 = *reinterpret_cast<const int4*>(t2 + 8 * hc + 4);
+                            voff[c][4 * hc + 0] = ((unsigned)(hh ? pa4.y : pa4.x) << 9) + cK[0];
+                            voff[c][4 * hc + 1] = ((unsigned)(hh ? pa4.w : pa4.z) << 9) + cK[1];
+                            voff[c][4 * hc + 2] = ((unsigned)(hh ? pb4.y : pb4.x) << 9) + cK[2];
+                            voff[c][4 * hc + 3] = ((unsigned)(hh ? pb4.w : pb4.z) << 9) + cK[3];
+                        }
+                        cqd[c] = (unsigned)((ccb[c] * H + h) * Lq + g * chunk + ccq[c]);
+                        lw_st(cc + 8u + (unsigned)((it[c] & 1) * 4), -1);   // consumed: the next stamp of this word (item it + 2's) is issued later
+                        ph[c] = 1;
+                    }
+                    // ---- K rows (ring read by the consumer up to item it - 1), then V rows
+                    if ((ph[c] == 1 && lw_ld(cc + 16u) >= it[c]) || (ph[c] == 2 && lw_ld(cc + 20u) >= it[c])) {
+                        const bool isv = ph[c] == 2;
+                        const float* base = reinterpret_cast<const float*>(lw_uniform_ptr(reinterpret_cast<const char*>((isv ? v0 : k0) + (size_t)ccb[c] * pair_pitch)));
+                        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(kring[c] + (isv ? 8192u : 0u)));
+                        const unsigned long long t0_ = __builtin_readcyclecounter();
+                        glds_chunk(base, voff[c][0], voff[c][1], voff[c][2], voff[c][3], dst);
+                        glds_chunk(base, voff[c][4], voff[c][5], voff[c][6], voff[c][7], dst + 4096u);
+                        stamp(cqd[c], ctrl[c] + (isv ? 4u : 0u));   // klanded / vlanded
+                        l_iss += __builtin_readcyclecounter() - t0_;
+                        outst += 9; issued = true;
+                        if (isv) {
+                            ph[c] = 0; ++it[c];
+                            ccq[c] += stride;
+                            while (ccq[c] >= cnt) { ccq[c] -= cnt; ++ccb[c]; }
+                        } else ph[c] = 2;
                     }
                 }
-                all_done = all_done && s[c] >= T[c] && n[c] >= 4 * T[c];
             }
-            if (all_done && flen == 0) break;   // everything issued AND retired (= published)
-            // ---- (c) retire in order: keep at most DEPTH groups in flight behind the ones just issued; when nothing could be issued,
-            //      retire the oldest one at once (its owner is probably waiting for it)
-            bool retired = false;
-            while (flen > (issued ? DEPTH : 0)) {
-                const int code = (int)(fifo & 7ull), owner = code & 3, size = (code & 4) ? 4 : 1;
-                { const unsigned long long t0_ = __builtin_readcyclecounter(); vmwait_dyn(outst - size); l_blk += __builtin_readcyclecounter() - t0_; }
-                fifo >>= 3; --flen; outst -= size;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (owner == c) {
-                        if (code & 4) { if (lane == 0) ctrl[c * 4 + 0] = ctrl[c * 4 + 0] + 1; }
-                        else ++sl[c];
-                    }
-                retired = true;
-                if (!issued) break;   // one at a time while idle: a slot may have been freed meanwhile
+            if (all_done) break;
+            if (outst > 36) {   // vmcnt is a 6-bit counter
+                const unsigned long long t0_ = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                l_blk += __builtin_readcyclecounter() - t0_;
+                outst = 24;
             }
-            if (issued || retired) spins = 0;
+            if (issued) spins = 0;
             else {
                 const unsigned long long t0_ = __builtin_readcyclecounter();
                 __builtin_amdgcn_s_sleep(1);
@@ -194,10 +230,8 @@ __global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
                 if (++spins > LW_SPIN_MAX) { if (a.err && lane == 0) *a.err = 1; break; }
             }
         }
-        if (a.dbg && lane == 0) {
-            atomicAdd(a.dbg + 5, l_blk); atomicAdd(a.dbg + 6, l_idle); atomicAdd(a.dbg + 7, (unsigned long long)(__builtin_readcyclecounter() - l_begin));
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.dbg && lane == 0) { atomicAdd(a.dbg + 5, l_blk); atomicAdd(a.dbg + 2, l_iss); atomicAdd(a.dbg + 6, l_idle); atomicAdd(a.dbg + 7, (unsigned long long)(__builtin_readcyclecounter() - l_begin)); }
         return;
     }
 
@@ -206,42 +240,43 @@ __global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
     const int t = (blockIdx.x >> 3) * NC + c;
     const int T = items_of(t);
     if (T == 0) return;
-    float* ring = smem + c * CW;
-    float* Pld = ring + SLOTS * 1024;
+    float* ring = smem + c * CW;        // K rows: 64 x 128 B (XOR-swizzled 16-byte units); V rows behind them
+    float* Pld = ring + 4096;
     float* stg = Pld + P_FLOATS;
-    volatile int* my = ctrl + c * 4;
+    const unsigned my = lds_byte_addr(smem + c * CW + CW - 8);
     unsigned va[8];    // V chunk: byte offset of V[row 2 mm + lane/32][d = lane%32] for mm % 8 == x, minus mm * 256
 #pragma unroll
     for (int x = 0; x < 8; ++x) va[x] = (unsigned)((lane >> 5) * 128 + ((((lane & 31) >> 2) ^ x) * 16) + (lane & 3) * 4);
     const float* pa = Pld + ((lane & 3) * 2 + (lane >> 5)) * PST;   // operand A of the V chunks: P[child lane%4][parity lane/32][.]
+    const char* kb = reinterpret_cast<const char*>(ring) + lane * 128;
     int cb = t / cnt, cq = t % cnt, cy = (g * chunk + cq) / wq, cx = (g * chunk + cq) % wq;
     const int sy = stride / wq, sx = stride % wq;
     bool failed = false;
-    unsigned long long w_acc[3] = {0, 0, 0};
+    unsigned long long w_acc[2] = {0, 0};
     const unsigned long long t_begin = __builtin_readcyclecounter();
-    auto wait_landed = [&](int need) {
+    auto wait_for = [&](int word, int which) {
+        const unsigned long long t0_ = __builtin_readcyclecounter();
         int spins = 0;
-        while (my[0] < need) {
+        while (lw_ld(my + (unsigned)word * 4u) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > LW_SPIN_MAX) { failed = true; break; }
         }
         asm volatile("" ::: "memory");
+        w_acc[which] += __builtin_readcyclecounter() - t0_;
     };
     for (int i = 0; i < T && !failed; ++i) {
         const int b = cb, l00 = 2 * cy * a.w0 + 2 * cx;
         const float* qs = stg + (i & 1) * STG;
-        // ---- K pass: candidates 0..31 in slot (4 i) % 3, 32..63 in slot (4 i + 1) % 3
-        { const unsigned long long t0_ = __builtin_readcyclecounter(); wait_landed(4 * i + 2); w_acc[0] += __builtin_readcyclecounter() - t0_; }
-        const int s0 = (4 * i) % SLOTS, s1 = (4 * i + 1) % SLOTS;
-        const char* kb = reinterpret_cast<const char*>(ring) + (lane < 32 ? s0 : s1) * 4096 + (lane & 31) * 128;
-        const float acc_cur = a.acc_in ? qs[160 + (lane & 31)] : 0.f;   // final[parent] of the item for d = lane % 32 (:277)
+        // ---- K pass (the K stamp lies behind the item's staging instruction: queries and final[parent] are there too)
+        wait_for(0, 0);
+        const float acc_cur = a.acc_in ? qs[144 + (lane & 31)] : 0.f;   // final[parent] of the item for d = lane % 32 (:277)
         f32x4 qa[8], kr[8];   // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row
 #pragma unroll
         for (int u = 0; u < 8; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * 32 + ((u ^ ((lane & 3) >> 1)) * 4));
 #pragma unroll
         for (int u = 0; u < 8; ++u) kr[u] = *reinterpret_cast<const f32x4*>(kb + ((u ^ ((lane >> 1) & 7)) * 16));
         lds_reads_done();
-        if (lane == 0) my[1] = 4 * i + 2;
+        { lw_st(my, -1); lw_st(my + 16u, i + 1); }   // the K ring is free (LDS operations of a wave execute in order)
         f32x4 c4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) c4[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -273,15 +308,15 @@ __global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
             *reinterpret_cast<f32x2*>(Pld + (f * 2 + 1) * PST + 2 * j) = (f32x2){ps[1] * rinv, ps[3] * rinv};
             wave_lds_fence();
         }
-        if (lane == 0) my[2] = i + 1;   // this item's staging area is no longer needed
-        // ---- V chunks
+        lw_st(my + 24u, i + 1);   // this item's staging area is no longer needed
+        // ---- V rows
+        wait_for(1, 1);
         f32x4 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            { const unsigned long long t0_ = __builtin_readcyclecounter(); wait_landed(4 * i + 3 + cc); w_acc[1 + cc] += __builtin_readcyclecounter() - t0_; }
-            const char* sb = reinterpret_cast<const char*>(ring) + ((4 * i + 2 + cc) % SLOTS) * 4096;
+            const char* sb = reinterpret_cast<const char*>(ring) + 8192 + cc * 4096;
             f32x4 pv[4];   // operand A of MFMA mm: P[child lane%4][parity lane/32][16 cc + mm]
 #pragma unroll
             for (int k = 0; k < 4; ++k) pv[k] = *reinterpret_cast<const f32x4*>(pa + 16 * cc + 4 * k);
@@ -289,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
 #pragma unroll
             for (int mm = 0; mm < 16; ++mm) vb[mm] = *reinterpret_cast<const float*>(sb + va[mm & 7] + mm * 256);
             lds_reads_done();
-            if (lane == 0) my[1] = 4 * i + 3 + cc;
+            if (cc == 1) { lw_st(my + 4u, -1); lw_st(my + 20u, i + 1); }   // the V ring is free
 #pragma unroll
             for (int mm = 0; mm < 16; ++mm)
                 acc[mm & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(pv[mm >> 2][mm & 3], vb[mm], acc[mm & 3], 0, 0, 0);
@@ -324,7 +359,7 @@ __global__ __launch_bounds__(256, 3) void fine_lw_kernel(const FineLwArgs a) {
     }
     if (failed && a.err && lane == 0) *a.err = 1;
     if (a.dbg && lane == 0) {
-        atomicAdd(a.dbg + 0, w_acc[0]); atomicAdd(a.dbg + 1, w_acc[1]); atomicAdd(a.dbg + 2, w_acc[2]);
+        atomicAdd(a.dbg + 0, w_acc[0]); atomicAdd(a.dbg + 1, w_acc[1]);
         atomicAdd(a.dbg + 3, (unsigned long long)(__builtin_readcyclecounter() - t_begin)); atomicAdd(a.dbg + 4, (unsigned long long)T);
     }
 }
@@ -335,37 +370,55 @@ int casmtr_qta_fine_level_lw(const float* q, const float* key, const float* valu
     if (Kp != 16 || (H != 8 && H != 4 && H != 2 && H != 1) || (h0 & 1) || (w0 & 1) || (h1 & 1) || (w1 & 1)) return CASMTR_ERR_UNSUPPORTED;
     const long long lq0 = (long long)(h0 / 2) * (w0 / 2), lq1 = (long long)(h1 / 2) * (w1 / 2);
     if (lq1 >= (1 << 22) || (long long)B * H * lq0 * 512 >= (1ll << 32)) return CASMTR_ERR_UNSUPPORTED;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return CASMTR_ERR_UNSUPPORTED;
     FineLwArgs a{};
-    a.q = q; a.key = key; a.value = value; a.parents = parents; a.acc_in = acc_in; a.message = message; a.acc_out = acc_out; a.err = nullptr;
+    a.q = q; a.key = key; a.value = value; a.parents = parents; a.acc_in = acc_in; a.message = message; a.acc_out = acc_out;
+    a.err = nullptr; a.dbg = nullptr;
+    static int* seq_tab = nullptr;
+    if (getenv("CASMTR_LW_SEQ")) {
+        if (!seq_tab) {
+            (void)hipMalloc(&seq_tab, 256 * 2048 * sizeof(int));
+            int* hbuf = (int*)malloc(256 * 2048 * sizeof(int));
+            for (int i = 0; i < 256 * 2048; ++i) hbuf[i] = (i & 2047) + 1;
+            (void)hipMemcpy(seq_tab, hbuf, 256 * 2048 * sizeof(int), hipMemcpyHostToDevice);
+            free(hbuf);
+        }
+        a.seq = seq_tab;
+    }
     a.temp = temp; a.w_level = w_level; a.B = B; a.h0 = h0; a.w0 = w0; a.H = H; a.nquads = (int)lq0; a.lq1 = (int)lq1;
-    constexpr size_t lds = sizeof(float) * 3 * (3 * 1024 + 8 * 36 + 2 * 256) + 64;
-    static int resident[CASMTR_MAX_DEVICES] = {0};
+    const char* en = getenv("CASMTR_LW_NC");   // measurement knob: consumers per loader
+    const int LW_NC = en && en[0] == '1' ? 1 : en && en[0] == '3' ? 3 : 2;
+    const size_t lds = sizeof(float) * LW_NC * LW_CW;
+    static int resident[3][CASMTR_MAX_DEVICES] = {{0}};
     int res = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fine_lw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (const int r = resident_workgroups(resident, fine_lw_kernel, 256, lds, &res)) return r;
+    auto kern = LW_NC == 1 ? fine_lw_kernel<1, 8> : LW_NC == 3 ? fine_lw_kernel<3, 2> : fine_lw_kernel<2, 4>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int r = resident_workgroups(resident[LW_NC - 1], kern, 64 * (1 + LW_NC), lds, &res)) return r;
     long long blocks = res;
     const char* ev = getenv("CASMTR_LW_BLOCKS");   // measurement knob: workgroups in the persistent grid (multiple of 8)
     if (ev && atoi(ev) > 0 && atoi(ev) < blocks) blocks = atoi(ev) / 8 * 8;
     const int G = 8 / H;
     const long long per_xcd = (long long)B * ((lq0 + G - 1) / G);
-    if (blocks / 8 * 3 > per_xcd) blocks = (per_xcd + 2) / 3 * 8;
+    if (blocks / 8 * LW_NC > per_xcd) blocks = (per_xcd + LW_NC - 1) / LW_NC * 8;
     if (blocks < 8) blocks = 8;
-    static unsigned long long* dbg = nullptr;
+    static unsigned long long* dbg[CASMTR_MAX_DEVICES] = {nullptr};
     if (getenv("CASMTR_LW_DEBUG")) {
-        if (!dbg) (void)hipMalloc(&dbg, 8 * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg, 0, 8 * sizeof(unsigned long long), s);
-        a.dbg = dbg;
+        if (!dbg[dev]) (void)hipMalloc(&dbg[dev], 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg[dev], 0, 8 * sizeof(unsigned long long), s);
+        a.dbg = dbg[dev];
     }
     prof_symbol_args(CASMTR_PROF_QTA_FINE, "%s", "");
-    CASMTR_LAUNCH_TIMED(CASMTR_PROF_QTA_FINE, fine_lw_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_QTA_FINE, kern, dim3((unsigned)blocks), dim3(64 * (1 + LW_NC)), lds, s, a);
     CASMTR_CHECK_LAUNCH();
     if (a.dbg) {
         unsigned long long hdbg[8];
         (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(hdbg, dbg, sizeof hdbg, hipMemcpyDeviceToHost);
-        const double it = (double)(hdbg[4] ? hdbg[4] : 1), nl = (double)blocks;
-        fprintf(stderr, "fine_lw: %lld workgroups; per item: wait K %.0f, V0 %.0f, V1 %.0f of %.0f cycles; loader: blocked in vmcnt %.0f %%, idle %.0f %% of %.0f cycles\n",
-                blocks, hdbg[0] / it, hdbg[1] / it, hdbg[2] / it, hdbg[3] / it, 100.0 * hdbg[5] / (double)hdbg[7], 100.0 * hdbg[6] / (double)hdbg[7], hdbg[7] / nl);
+        (void)hipMemcpy(hdbg, a.dbg, sizeof hdbg, hipMemcpyDeviceToHost);
+        const double it = (double)(hdbg[4] ? hdbg[4] : 1);
+        fprintf(stderr, "fine_lw: %lld workgroups (%d resident); per item: wait K %.0f, V %.0f of %.0f cycles; loader idle %.0f %%, in vmcnt %.0f %%, issuing 9-instruction groups %.0f %% of %.0f cycles\n", blocks, res,
+                hdbg[0] / it, hdbg[1] / it, hdbg[3] / it, 100.0 * hdbg[6] / (double)(hdbg[7] ? hdbg[7] : 1), 100.0 * hdbg[5] / (double)(hdbg[7] ? hdbg[7] : 1),
+                100.0 * hdbg[2] / (double)(hdbg[7] ? hdbg[7] : 1), hdbg[7] / (double)blocks);
     }
     return 0;
 }

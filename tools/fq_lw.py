@@ -1,5 +1,5 @@
 """Loader-wave kernel of the finest QTAttB level (csrc/fine_lw.hip, CASMTR_FQ_LW=1) against fine_quad_kernel<1,false,true>: bit-equality of
-the results and us per launch as a function of the persistent grid (CASMTR_LW_BLOCKS workgroups of 1 loader + 3 consumer waves)."""
+the results and us per launch as a function of the persistent grid (CASMTR_LW_BLOCKS workgroups of 1 loader + 2 consumer waves)."""
 import os
 import sys
 
@@ -37,7 +37,8 @@ def timeit(n=20):
 
 print(f"fine_quad_kernel: {timeit():.1f} us per launch", flush=True)
 os.environ["CASMTR_FQ_LW"] = "1"
-for blocks in (None, 768, 640, 512, 384, 256):
+for nc, blocks in ((2, None), (2, 512), (1, None), (1, 1024), (3, None)):
+    os.environ["CASMTR_LW_NC"] = str(nc)
     if blocks is None:
         os.environ.pop("CASMTR_LW_BLOCKS", None)
     else:
@@ -49,4 +50,4 @@ for blocks in (None, 768, 640, 512, 384, 256):
     torch.cuda.synchronize()
     same = all(torch.equal(out[kk], ref[kk]) for kk in ("acc", "message") if ref.get(kk) is not None and out.get(kk) is not None)
     md = max(float((out[kk] - ref[kk]).abs().max()) for kk in ("acc", "message") if ref.get(kk) is not None)
-    print(f"fine_lw_kernel, {blocks or 'resident'} workgroups: bit-equal {same} (max abs diff {md:.2e}); {timeit():.1f} us per launch", flush=True)
+    print(f"fine_lw_kernel, {nc} consumers per loader, {blocks or 'resident'} workgroups: bit-equal {same} (max abs diff {md:.2e}); {timeit():.1f} us per launch", flush=True)
