@@ -16,8 +16,7 @@
 // Hand-shakes without a single blocking wait in the loader: the loader never waits for its own DMAs.  Behind the eight gather
 // instructions of a K (or V) set, and behind a staging instruction, it issues ONE more LDS-DMA instruction with a single active lane
 // that copies a word known to be >= 0 (the first index of the item's own parent list: a line the staging instruction has just
-// fetched, different for every item -- a shared table of sequence numbers made one L2 line the hot spot of the whole chip) over the
-// consumer's `klanded` / `vlanded` / `slanded` stamp word, which holds -1.  A wave's vector-memory operations return in order (that
+// fetched) over the consumer's `klanded` / `vlanded` / `slanded` stamp word, which holds -1.  A wave's vector-memory operations return in order (that
 // is what vmcnt counts), so when the stamp is >= 0 the rows are in LDS: the hardware publishes the landing.  The reader of a stamp
 // resets it to -1 before it frees the ring.  In the other direction the consumer bumps `kfreed` / `vfreed` / `sfreed` with plain LDS
 // stores once its reads have completed (lgkmcnt(0)).  The loader walks its two consumers round robin and issues whatever is allowed:
@@ -26,9 +25,16 @@
 //   V rows of item i       : after its K rows, and vfreed >= i
 // so the K rows of item i + 1 are on their way while item i is still in its softmax, its V rows while item i + 1 runs its K pass.
 // Every spin is bounded: a protocol error would end the kernel with wrong results and a raised flag, not hang the device.
-// (First version, commit fe1e2be: 1 loader + 3 consumers, three 4 KB slots each, landings published by the loader after an in-order
-// `s_waitcnt vmcnt` retire through a FIFO of group codes: 1.2 ms per launch, the loader wave executing ~7600 cycles of its own
-// bookkeeping per item served.)
+// The counters are read and written with explicit DS instructions: through a generic pointer the compiler emits FLAT loads, and the
+// s_waitcnt vmcnt(0) it puts behind each one made every poll wait for all of the wave's gathers (first version, commit fe1e2be:
+// 1 loader + 3 consumers, landings published after an in-order `s_waitcnt vmcnt` retire through a FIFO of group codes, 1.2 ms per
+// launch; this version with FLAT polls 0.5 ms).
+//
+// Result: bit-equal to fine_quad_kernel<1, false, true>, 270-280 us per launch against its 220-240 on the same
+// boxes.  A K or V ring is reserved from the moment its gathers are issued: ~5000 cycles of flight for ~600 cycles of use, the same
+// LDS bytes x time per item as fine_quad's, and the consumers' own ~2800 issue cycles per item are what a SIMD can do anyway (four
+// SIMDs x 1 item / 2800 cycles = 197 us: the shipped kernel sits on that bound, not on the gather).  Kept as a measurement
+// variant: CASMTR_FQ_VARIANT=lw, tools/fq_lw.py.
 #include <stdio.h>
 #include <stdlib.h>
 #include "quad_common.hpp"
@@ -44,7 +50,6 @@ struct FineLwArgs {
     const float* acc_in;     // nullable [B,Lq0,H*32]
     float* message;          // nullable [B,L,H*32]
     float* acc_out;          // nullable [B,L,H*32]
-    const int* seq;          // A/B: nullable replicated table seq[r][k] = k + 1 (r < 256, k < 2048)
     int* err;                // nullable: set to 1 when a bounded spin ran out
     unsigned long long* dbg; // nullable (CASMTR_LW_DEBUG): [0] consumer cycles waiting for K, [1] for V, [3] total, [4] items; [6] loader idle, [7] loader total
     float temp, w_level;
@@ -139,18 +144,13 @@ __global__ __launch_bounds__(64 * (1 + NC), WGS) void fine_lw_kernel(const FineL
         const bool hh = lane >> 5;
         // one LDS-DMA instruction with ONE active lane: the first word of the item's parent list (an index >= 0) -> the stamp word at LDS byte
         // address `dst`, which held -1; it lands behind everything this wave issued before
-        const unsigned long long pbase = (unsigned long long)a.parents;
-        const unsigned long long sq = (unsigned long long)a.seq + (unsigned long long)((blockIdx.x & 255) * 2048) * 4;
-        unsigned nstamp = 0;
-        const char* const seqb = lw_uniform_ptr(reinterpret_cast<const char*>(a.seq) + (size_t)((blockIdx.x & 255) * 2048) * 4);
         const char* const parb = lw_uniform_ptr(reinterpret_cast<const char*>(a.parents));
         auto stamp = [&](unsigned qd, unsigned dst) {
-            const unsigned off = a.seq ? ((nstamp++) & 2047u) * 4u : qd * (unsigned)(Kp * 4);
-            const char* const sb = a.seq ? seqb : parb;
+            const unsigned off = qd * (unsigned)(Kp * 4);
             const unsigned d = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
             unsigned long long keep;
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
-                         : "=&s"(keep) : "v"(off), "s"(sb), "s"(d) : "memory");
+                         : "=&s"(keep) : "v"(off), "s"(parb), "s"(d) : "memory");
         };
         unsigned cqd[NC];   // (pair, head, quad) index of the item being gathered
         int spins = 0, outst = 0;
@@ -375,17 +375,6 @@ int casmtr_qta_fine_level_lw(const float* q, const float* key, const float* valu
     FineLwArgs a{};
     a.q = q; a.key = key; a.value = value; a.parents = parents; a.acc_in = acc_in; a.message = message; a.acc_out = acc_out;
     a.err = nullptr; a.dbg = nullptr;
-    static int* seq_tab = nullptr;
-    if (getenv("CASMTR_LW_SEQ")) {
-        if (!seq_tab) {
-            (void)hipMalloc(&seq_tab, 256 * 2048 * sizeof(int));
-            int* hbuf = (int*)malloc(256 * 2048 * sizeof(int));
-            for (int i = 0; i < 256 * 2048; ++i) hbuf[i] = (i & 2047) + 1;
-            (void)hipMemcpy(seq_tab, hbuf, 256 * 2048 * sizeof(int), hipMemcpyHostToDevice);
-            free(hbuf);
-        }
-        a.seq = seq_tab;
-    }
     a.temp = temp; a.w_level = w_level; a.B = B; a.h0 = h0; a.w0 = w0; a.H = H; a.nquads = (int)lq0; a.lq1 = (int)lq1;
     const char* en = getenv("CASMTR_LW_NC");   // measurement knob: consumers per loader
     const int LW_NC = en && en[0] == '1' ? 1 : en && en[0] == '3' ? 3 : 2;

@@ -563,7 +563,10 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     flush();
 }
 
-// fine_lw.hip
+// fine_vs.hip, fine_lw.hip
+int casmtr_qta_fine_level_vs(const float* q, const float* key, const float* value, const int32_t* parents, float temp, float w_level,
+                             const float* acc_in, float* message, float* acc_out, int B, int h0, int w0, int h1, int w1, int H, int Kp,
+                             hipStream_t s);
 int casmtr_qta_fine_level_lw(const float* q, const float* key, const float* value, const int32_t* parents, float temp, float w_level,
                              const float* acc_in, float* message, float* acc_out, int B, int h0, int w0, int h1, int w1, int H, int Kp,
                              hipStream_t s);
@@ -641,10 +644,14 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
     { const char* ev = getenv("CASMTR_FQ_FLAGS"); a.xflags = ev ? atoi(ev) : 0; }
     hipStream_t s = (hipStream_t)stream;
     const bool full = K == 64 || K == 128;
-    if (topk == 0 && K == 64) {   // the finest level of every shipped config: loader-wave specialisation (fine_lw.hip), bit-equal results
-        const char* ev = getenv("CASMTR_FQ_LW");
-        if (ev && ev[0] == '1') {
+    if (topk == 0 && K == 64) {   // the finest level of every shipped config
+        const char* ev = getenv("CASMTR_FQ_VARIANT");   // experiments of round 5, bit-equal results: "lw", "vs"
+        if (ev && ev[0] == 'l') {
             const int r = casmtr_qta_fine_level_lw(q, key, value, parents, temp, w_level, acc_in, message, acc_out, B, h0, w0, h1, w1, H, Kp, s);
+            if (r != CASMTR_ERR_UNSUPPORTED) return r;
+        }
+        if (ev && ev[0] == 'v') {
+            const int r = casmtr_qta_fine_level_vs(q, key, value, parents, temp, w_level, acc_in, message, acc_out, B, h0, w0, h1, w1, H, Kp, s);
             if (r != CASMTR_ERR_UNSUPPORTED) return r;
         }
     }
