@@ -38,8 +38,9 @@ constexpr int VS_WW = 2048 + VS_P_FLOATS + 3 * VS_STG;              // floats pe
 
 #define VS_LOAD(dst, off, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
 
-template <int NST, bool DBG>   // output stores per item (2 per written tensor); cycle counters
+template <int NST, int ABL>   // output stores per item (2 per written tensor); bit 0: cycle counters; other bits: ablations (timing only)
 __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
+    constexpr bool DBG = ABL & 1;
     constexpr int PST = VS_PST, P_FLOATS = VS_P_FLOATS, KS = VS_KS, STG = VS_STG, WW = VS_WW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -128,12 +129,12 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
     auto load_k = [&](int b) {
         const float* base = uniform_base(k0, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) VS_LOAD(kreg[j], voff[j], base);
+        for (int j = 0; j < 8; ++j) { if constexpr (ABL & 16) kreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; else VS_LOAD(kreg[j], voff[j], base); }
     };
     auto load_v = [&](int b) {
         const float* base = uniform_base(v0, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) VS_LOAD(vreg[j], voff[j], base);
+        for (int j = 0; j < 8; ++j) { if constexpr (ABL & 16) vreg[j] = (f32x4){1.f, 0.f, 0.f, 0.f}; else VS_LOAD(vreg[j], voff[j], base); }
     };
 #define VS_LANDED(N)                                                                                                                       \
     asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                                 \
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
         }
         // ---- K rows -> LDS; the next item's K rows take off
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(wr + 1024 * j) = kreg[j];
+        for (int j = 0; j < ((ABL & 32) ? 1 : 8); ++j) *reinterpret_cast<f32x4*>(wr + 1024 * j) = kreg[j];
         const bool more = i + 1 < T;
         if (more) { offsets(b1); load_k(nx.b); }
         if (i + 2 < T) { stage(st, b2); advance(st); }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
         // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row.  Two halves of the feature dimension: the rows
         // in flight take 64 registers of the 168
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = (ABL & 8) ? 1 : 0; half < 2; ++half) {
             f32x4 qa[4], kr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const f32x4*>(qs + (lane & 3) * 32 + (((4 * half + u) ^ ((lane & 3) >> 1)) * 4));
@@ -192,11 +193,11 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
                 lds_reads_done();
                 wave_lds_fence();
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(wr + 1024 * j) = vreg[j];
+                for (int j = 0; j < ((ABL & 32) ? 1 : 8); ++j) *reinterpret_cast<f32x4*>(wr + 1024 * j) = vreg[j];
                 if (more) { load_v(nx.b); advance(nx); }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {   // no index depends on these logits: four interleaved partial d-chains
+            for (int u = 0; u < ((ABL & 8) ? 1 : 4); ++u) {   // no index depends on these logits: four interleaved partial d-chains
                 c4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].x, kr[u].x, c4[0], 0, 0, 0);
                 c4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].y, kr[u].y, c4[1], 0, 0, 0);
                 c4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[u].z, kr[u].z, c4[2], 0, 0, 0);
@@ -205,7 +206,10 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
             asm volatile("" ::: "memory");
         }
         // ---- softmax, one series (child) per 16-lane row (fine_quad.hip: softmax_select without the selection)
-        {
+        if constexpr (ABL & 2) {
+            Pld[lane] = (c4[0][0] + c4[1][1]) + (c4[2][2] + c4[3][3]);
+            wave_lds_fence();
+        } else {
             const int f = lane >> 4, j = lane & 15;
 #pragma unroll
             for (int ff = 0; ff < 4; ++ff) Pld[ff * KS + lane] = a.temp * ((c4[0][ff] + c4[1][ff]) + (c4[2][ff] + c4[3][ff]));
@@ -230,16 +234,16 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
+        for (int cc = (ABL & 4) ? 1 : 0; cc < 2; ++cc) {
             const char* sb = reinterpret_cast<const char*>(ring) + cc * 4096;
             f32x4 pv[4];   // operand A of MFMA mm: P[child lane%4][parity lane/32][16 cc + mm]
 #pragma unroll
             for (int k = 0; k < 4; ++k) pv[k] = *reinterpret_cast<const f32x4*>(pa + 16 * cc + 4 * k);
             float vb[16];
 #pragma unroll
-            for (int mm = 0; mm < 16; ++mm) vb[mm] = *reinterpret_cast<const float*>(sb + va[mm & 7] + mm * 256);
+            for (int mm = 0; mm < ((ABL & 4) ? 1 : 16); ++mm) vb[mm] = *reinterpret_cast<const float*>(sb + va[mm & 7] + mm * 256);
 #pragma unroll
-            for (int mm = 0; mm < 16; ++mm)
+            for (int mm = 0; mm < ((ABL & 4) ? 1 : 16); ++mm)
                 acc[mm & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(pv[mm >> 2][mm & 3], vb[mm], acc[mm & 3], 0, 0, 0);
         }
         lds_reads_done();
@@ -256,8 +260,10 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
             const int hi = lane >> 5;
             const float vA = hi ? tot[2] : tot[0], vB = hi ? tot[3] : tot[1];
             const size_t o = ((size_t)b * L + l00 + hi * a.w0) * HD + h * 32 + (lane & 31);
-            if (a.message) { a.message[o] = vA; a.message[o + HD] = vB; }
-            if (a.acc_out) {   // separate multiply and add (:277-281)
+            if ((ABL & 64) && vA != 12345.f) {
+            } else if (a.message) { a.message[o] = vA; a.message[o + HD] = vB; }
+            if ((ABL & 64) && vB != 12345.f) {
+            } else if (a.acc_out) {   // separate multiply and add (:277-281)
                 a.acc_out[o] = acc_cur + vA * a.w_level;
                 a.acc_out[o + HD] = acc_cur + vB * a.w_level;
             }
@@ -291,8 +297,8 @@ int casmtr_qta_fine_level_vs(const float* q, const float* key, const float* valu
     constexpr size_t lds = sizeof(float) * 4 * VS_WW;
     static int resident[CASMTR_MAX_DEVICES] = {0};
     int res = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fine_vs_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (const int r = resident_workgroups(resident, fine_vs_kernel<0, false>, 256, lds, &res)) return r;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fine_vs_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int r = resident_workgroups(resident, fine_vs_kernel<0, 0>, 256, lds, &res)) return r;
     long long blocks = res;
     const char* ev = getenv("CASMTR_VS_BLOCKS");   // measurement knob: workgroups in the persistent grid (multiple of 8)
     if (ev && atoi(ev) > 0 && atoi(ev) < blocks) blocks = atoi(ev) / 8 * 8;
@@ -314,10 +320,19 @@ int casmtr_qta_fine_level_vs(const float* q, const float* key, const float* valu
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fine_vs_kernel<N, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         CASMTR_LAUNCH_TIMED(CASMTR_PROF_QTA_FINE, (fine_vs_kernel<N, D>), dim3((unsigned)blocks), dim3(256), lds, s, a);                   \
     } while (0)
-    if (a.dbg) VS_GO(0, true);
-    else if (nst == 4) VS_GO(4, false);
-    else if (nst == 2) VS_GO(2, false);
-    else VS_GO(0, false);
+    const char* ea = getenv("CASMTR_VS_ABLATE");   // measurement knob (wrong results): 2 no softmax, 4 no V pass, 8 no K pass, 16 no row loads, 32 no row writes to LDS, 64 no stores
+    const int abl = ea && nst == 4 ? atoi(ea) : 0;
+    if (a.dbg) VS_GO(0, 1);
+    else if (abl == 2) VS_GO(4, 2);
+    else if (abl == 4) VS_GO(4, 4);
+    else if (abl == 8) VS_GO(4, 8);
+    else if (abl == 16) VS_GO(4, 16);
+    else if (abl == 32) VS_GO(4, 32);
+    else if (abl == 64) VS_GO(0, 64);
+    else if (abl == 126) VS_GO(0, 126);
+    else if (nst == 4) VS_GO(4, 0);
+    else if (nst == 2) VS_GO(2, 0);
+    else VS_GO(0, 0);
 #undef VS_GO
     CASMTR_CHECK_LAUNCH();
     if (a.dbg) {
