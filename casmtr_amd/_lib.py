@@ -65,7 +65,7 @@ SIGNATURES = {
     "casmtr_prof_symbol": (C.c_char_p, [_I]),
     "casmtr_prof_read_all": (_I, [_I, C.POINTER(C.c_double), _I]),
 }
-PROF_COUNT = 20
+PROF_COUNT = 21
 
 
 def prof_enable(on: bool):

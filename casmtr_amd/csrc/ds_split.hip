@@ -152,16 +152,14 @@ __device__ __forceinline__ void glds_2k(const char* base, unsigned voff, unsigne
 // SIGN of the staged factors (facA / facB negative = masked row / column) instead of byte loads, ds_read_b128 transposes.
 //   scratch: 4 x [32][68] wave-private slabs, then rowx[2][128][2], colx[2][128][2]
 #define DS16_WL 68
-template <bool MASKED>
-__device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* scratch, const float* facA, const float* facB,
-                                                  float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ, int L, int S,
-                                                  int NJB, int NIB) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+template <bool MASKED, bool WST = false>
+__device__ __forceinline__ void ds_split_epilogue_wave(f32x16 (&acc)[2][2], float* wl, float* rowx, float* colx, const float* facA,
+                                                       const float* facB, float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ,
+                                                       int L, int S, int NIB, int wr, int wc) {
+    // steps 1-3 for the 64 x 64 part (wr, wc) of the 128 x 128 tile (tI, tJ): wl = this wave's [32][68] slab, rowx [2 wc][128][2],
+    // colx [2 wr][128][2] the tile's exchange areas, facA / facB the tile's 128 row / column factors
+    const int lane = threadIdx.x & 63;
     const int hi = lane >> 5, ln = lane & 31;
-    float* wl = scratch + wave * (32 * DS16_WL);
-    float* rowx = scratch + 4 * 32 * DS16_WL;           // [2 wc][128 rows][2]
-    float* colx = rowx + 2 * 128 * 2;                   // [2 wr][128 cols][2]
     // addresses: wave-uniform base (SGPR pair) + 32-bit byte offset (lane part + scalar row part): no 64-bit VALU arithmetic
     char* tile = const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(sim + ((size_t)b * L + tI * DS_BM + wr * 64) * S + tJ * DS_BN + wc * 64)));
     char* grp = const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(w.cg_m + (((size_t)b * NIB + tI) * 8 + wr * 4) * S + tJ * DS_BN + wc * 64)));
@@ -195,8 +193,10 @@ __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* sc
                 float x = __fmul_rn(__fmul_rn(acc[ti][tj][r], __builtin_fabsf(f)), fbv[tj]);
                 if (MASKED && (__float_as_int(f) < 0 || cmask[tj])) x = NEG_FILL;
                 const char* rowbase = tile + (size_t)(ti * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;    // wave-uniform
-                if (tj == 0) asm volatile("global_store_dword %0, %1, %2" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
-                else asm volatile("global_store_dword %0, %1, %2 offset:128" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
+                if constexpr (!WST) {
+                    if (tj == 0) asm volatile("global_store_dword %0, %1, %2" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
+                    else asm volatile("global_store_dword %0, %1, %2 offset:128" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
+                }
                 xv[ti][tj][r] = x;
                 g16 = fmaxf(g16, x);
             }
@@ -231,6 +231,16 @@ __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* sc
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (WST) {   // the slab's rows as 256-byte runs: 8 stores of 1 KB instead of 32 of 256 B
+            const float* sp = wl + (lane >> 4) * DS16_WL + (lane & 15) * 4;
+            const unsigned so = (unsigned)((lane >> 4) * S + (lane & 15) * 4) * 4u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(sp + 4 * k * DS16_WL);
+                const char* rowbase = tile + (size_t)(ti * 32 + 4 * k) * row_bytes;    // wave-uniform
+                asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(so), "v"(q4), "s"(rowbase) : "memory");
+            }
+        }
         const f32x4* rp = reinterpret_cast<const f32x4*>(wl + ln * DS16_WL + hi * 32);
         f32x4 v[8];
 #pragma unroll
@@ -251,22 +261,36 @@ __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* sc
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
-    // ---- 4. combine the two waves that share a row (wc = 0,1) / a column (wr = 0,1)
-    {
-        const float* x0 = (tid < 128 ? rowx : colx) + (tid & 127) * 2;
-        const float* x1 = x0 + 128 * 2;
-        const float ma = x0[0], mb = x1[0];
-        const float mm = fmaxf(ma, mb);
-        const float tot = x0[1] * __expf(ma - mm) + x1[1] * __expf(mb - mm);
-        if (tid < 128) {
-            const size_t o = ((size_t)b * NJB + tJ) * L + tI * DS_BM + tid;
-            w.rp_m[o] = mm; w.rp_s[o] = tot;
-        } else {
-            const size_t o = ((size_t)b * NIB + tI) * S + tJ * DS_BN + tid - 128;
-            w.cp_m[o] = mm; w.cp_s[o] = tot;
-        }
+}
+
+// step 4: combine the two parts that share a row (wc = 0,1) / a column (wr = 0,1); role < 128: row `role`, else column role - 128
+__device__ __forceinline__ void ds_split_epilogue_combine(const float* rowx, const float* colx, const DsWs& w, int b, int tI, int tJ, int L,
+                                                          int S, int NJB, int NIB, int role) {
+    const float* x0 = (role < 128 ? rowx : colx) + (role & 127) * 2;
+    const float* x1 = x0 + 128 * 2;
+    const float ma = x0[0], mb = x1[0];
+    const float mm = fmaxf(ma, mb);
+    const float tot = x0[1] * __expf(ma - mm) + x1[1] * __expf(mb - mm);
+    if (role < 128) {
+        const size_t o = ((size_t)b * NJB + tJ) * L + tI * DS_BM + role;
+        w.rp_m[o] = mm; w.rp_s[o] = tot;
+    } else {
+        const size_t o = ((size_t)b * NIB + tI) * S + tJ * DS_BN + role - 128;
+        w.cp_m[o] = mm; w.cp_s[o] = tot;
     }
+}
+
+//   scratch: 4 x [32][68] wave-private slabs, then rowx[2][128][2], colx[2][128][2]
+template <bool MASKED, bool WST = false>
+__device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* scratch, const float* facA, const float* facB,
+                                                  float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ, int L, int S,
+                                                  int NJB, int NIB) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* rowx = scratch + 4 * 32 * DS16_WL;           // [2 wc][128 rows][2]
+    float* colx = rowx + 2 * 128 * 2;                   // [2 wr][128 cols][2]
+    ds_split_epilogue_wave<MASKED, WST>(acc, scratch + wave * (32 * DS16_WL), rowx, colx, facA, facB, sim, w, b, tI, tJ, L, S, NIB, wave >> 1, wave & 1);
+    __syncthreads();
+    ds_split_epilogue_combine(rowx, colx, w, b, tI, tJ, L, S, NJB, NIB, (int)threadIdx.x);
 }
 
 // 128 x 128 block tile, 4 waves x (64 x 64), k-stages of 16 (8 KB of A image + 8 KB of B image = half a 16 KB image chunk),
@@ -280,7 +304,7 @@ template <int NSTG>   // operand stages in LDS: 2 (prefetch distance 1, 40 KB) o
 __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
-                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB) {
+                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB, int skipI, int skipJ, int wst) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
     char* lds = reinterpret_cast<char*>(smem);
     float* facA = smem + ((NSTG == 3 ? DS16_LDS3 : DS16_LDS) - 2 * 128 * 4) / 4;
@@ -290,6 +314,7 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     const int st = t >> 6, wi = t & 63;
     const int tI = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
     if (tI >= NIB || tJ >= NJB) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
+    if (tI < skipI && tJ < skipJ) return;   // the interior belongs to ds_gemm16w_kernel
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
@@ -377,7 +402,10 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
     if (tI * DS_BM + DS_BM <= L && tJ * DS_BN + DS_BN <= S) {
-        if (any_masked) ds_split_epilogue<true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+        if (wst) {
+            if (any_masked) ds_split_epilogue<true, true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+            else ds_split_epilogue<false, true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+        } else if (any_masked) ds_split_epilogue<true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
         else ds_split_epilogue<false>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
     } else {   // edge tile: the general epilogue (bounds predication, masks from memory)
         if (tid < 128) facA[tid] = __builtin_fabsf(facA[tid]);
@@ -385,6 +413,134 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
         __syncthreads();
         ds_tile_epilogue<true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
     }
+}
+
+
+// The same GEMM with 128 x 64 WAVE tiles: block tile 256 x 128 = two vertically adjacent 128 x 128 tiles of the image layout, wave
+// (wrr, wc) owns the 128 rows of tile 2 tI2 + wrr and 64 columns.  Per k-stage a wave reads 12 KB of operands for 24 MFMAs instead of
+// 8 KB for 12: the 64 x 64 kernel's main loop runs at the LDS's 128 B/clk, this one has a third of that to
+// spare.  Stage = 8 KB of each A tile + 8 KB of B = 24 KB, three stages (prefetch distance 2), 128 accumulator registers: two
+// workgroups per CU.  Every accumulator sees the same MFMA sequence as in ds_gemm16_kernel and the epilogue is that kernel's, run
+// per 64 x 64 part (each wave does its parts (0, wc) and (1, wc) of its tile one after the other): bit-identical results.  Only
+// blocks whose 256 rows and 128 columns are all in range; ds_gemm16_kernel does the bottom and right strips.
+#define DS16W_STAGE 24576
+#define DS16W_LDS (3 * DS16W_STAGE + (256 + 128) * 4)
+__global__ __launch_bounds__(256, 2) void ds_gemm16w_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
+                                                            const float* __restrict__ fa, const float* __restrict__ fb, int have_mask,
+                                                            float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB,
+                                                            int NIB2, int NJBf, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 stages x (A0 | A1 | B) / epilogue scratch, then facA[256] | facB[128]
+    char* lds = reinterpret_cast<char*>(smem);
+    float* facA = smem + 3 * DS16W_STAGE / 4;
+    float* facB = facA + 256;
+    const int NSJ = (NJBf + 7) >> 3;
+    const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
+    const int st = t >> 6, wi = t & 63;
+    const int tI2 = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
+    if (tI2 >= NIB2 || tJ >= NJBf) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wrr = wave >> 1, wc = wave & 1;
+    bool masked = false;
+    {
+        const float f = fa[((size_t)b * NIB + 2 * tI2) * 128 + tid];   // the two tiles' factors are adjacent; sign = padding mask
+        masked = have_mask && __float_as_int(f) < 0;
+        facA[tid] = f;
+        if (tid < 128) {
+            const float g = fb[((size_t)b * NJB + tJ) * 128 + tid];
+            masked = masked || (have_mask && __float_as_int(g) < 0);
+            facB[tid] = g;
+        }
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const char* a0_src = uniform_ptr(reinterpret_cast<const char*>(imgA) + ((size_t)b * NIB + 2 * tI2) * (size_t)KS * 8192);
+    const char* a1_src = a0_src + (size_t)KS * 8192;
+    const char* b_src = uniform_ptr(reinterpret_cast<const char*>(imgB) + ((size_t)b * NJB + tJ) * (size_t)KS * 8192);
+    const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_byte_addr(lds) + (unsigned)(wave * 2048)));
+    const int any_masked = __syncthreads_or(masked);   // (barrier: the factor loads above have completed before any DMA is outstanding)
+    auto issue = [&](int ks, int nb) {   // 6 DMA instructions per wave
+        const unsigned d = lds0 + (unsigned)(nb * DS16W_STAGE);
+        glds_2k(a0_src + (size_t)ks * 8192, voff, d);
+        glds_2k(a1_src + (size_t)ks * 8192, voff, d + 8192);
+        glds_2k(b_src + (size_t)ks * 8192, voff, d + 16384);
+    };
+    issue(0, 0);
+    if (KS > 1) issue(1, 1);
+    const int hi = lane >> 5, ln = lane & 31;
+    // fragment (ti, part): plane (kg = hi, part), row ti*32 + ln of this wave's A tile / column wc*64 + tj*32 + ln
+    const char* fa_base = lds + wrr * 8192 + (hi * 2) * 2048 + ln * 16;
+    const char* fb_base = lds + 16384 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
+    int buf = 0;
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) glds_wait<6>(); else glds_wait<0>();   // stage ks has landed when only stage ks + 1 is still in flight
+        lds_reads_done();
+        __builtin_amdgcn_s_barrier();   // everyone's share of stage ks has landed; everyone is done reading the buffer that is refilled next
+        asm volatile("" ::: "memory");
+        if (ks + 2 < KS) issue(ks + 2, buf >= 1 ? buf - 1 : 2);
+        h16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const char* pa = fa_base + buf * DS16W_STAGE + ti * 512;
+            ah[ti] = *reinterpret_cast<const h16x8*>(pa);
+            al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const char* pb = fb_base + buf * DS16W_STAGE + tj * 512;
+            bh[tj] = *reinterpret_cast<const h16x8*>(pb);
+            bl[tj] = *reinterpret_cast<const h16x8*>(pb + 2048);
+        }
+        if (dbg & 2) {   // timing experiment: no MFMAs
+            acc[0][0][0] += (float)ah[0][0] + (float)al[1][1] + (float)ah[2][2] + (float)al[3][3] + (float)bh[0][0] + (float)bl[1][1];
+            buf = buf == 2 ? 0 : buf + 1;
+            continue;
+        }
+        // small terms first (the order of ds_gemm16_kernel for every accumulator)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
+    if (dbg & 1) {   // timing experiment: no epilogue
+        float x = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x += acc[i][j][r];
+        if (x == 12345.f) sim[tid] = x;
+        return;
+    }
+    float* wl = smem + wave * (32 * DS16_WL);
+    float* xch = smem + 4 * 32 * DS16_WL;            // per tile: rowx [2 wc][128][2], colx [2 wr][128][2]
+    float* rowx = xch + wrr * 1024, *colx = rowx + 512;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        f32x16 (&part)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * v]);
+        if (any_masked) ds_split_epilogue_wave<true>(part, wl, rowx, colx, facA + wrr * 128, facB, sim, w, b, 2 * tI2 + wrr, tJ, L, S, NIB, v, wc);
+        else ds_split_epilogue_wave<false>(part, wl, rowx, colx, facA + wrr * 128, facB, sim, w, b, 2 * tI2 + wrr, tJ, L, S, NIB, v, wc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) ds_split_epilogue_combine(xch + sub * 1024, xch + sub * 1024 + 512, w, b, 2 * tI2 + sub, tJ, L, S, NJB, NIB, tid);
 }
 
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s) {
@@ -395,17 +551,32 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
     // ring buys.  A persistent variant with the epilogue software-pipelined under the next tile's k-stages (two accumulator sets, 2
     // workgroups per CU, 256 VGPRs with spills) was built and measured at 2.35 ms: the epilogue's slab traffic lands on the same
     // saturated LDS; it was removed again.
+    // Interior by ds_gemm16w_kernel (128 x 64 wave tiles) where at least one 256 x 128 block is whole, the bottom / right strips by
+    // ds_gemm16_kernel (CASMTR_DS_GEMM16_WIDE=0: everything by the latter; CASMTR_DS_GEMM16_STAGES=2: its two-stage form)
+    int skipI = 0, skipJ = 0;
+    const char* evs = getenv("CASMTR_DS_GEMM16_WST");
+    const int wst = evs && evs[0] == '1';
+    const char* evw = getenv("CASMTR_DS_GEMM16_WIDE");
+    const int NIB2 = L / 256, NJBf = S / DS_BN;
+    if (evw && evw[0] == '1' && NIB2 > 0 && NJBf > 0) {
+        const int nt = ((NJBf + 7) / 8) * ((NIB2 + 7) / 8) * 64;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DS16W_LDS);
+        CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16w_kernel, dim3(nt, B), dim3(256), DS16W_LDS, s, w.imgA, w.imgB, w.fa, w.fb, mask0 ? 1 : 0,
+                            sim, w, L, S, C / 16, NJB, NIB, NIB2, NJBf, g_debug_flags >> 12);
+        skipI = 2 * NIB2; skipJ = NJBf;
+        if (skipI >= NIB && skipJ >= NJB) { CASMTR_CHECK_LAUNCH(); return 0; }
+    }
     const char* ev3 = getenv("CASMTR_DS_GEMM16_STAGES");
     if (ev3 && ev3[0] == '2') {
         const size_t lds = DS16_LDS;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1,
-                            sim, w, L, S, C / 16, NJB, NIB);
+        CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
+                            mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, skipI, skipJ, wst);
     } else {
         const size_t lds = DS16_LDS3;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<3>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb, mask0, mask1,
-                            sim, w, L, S, C / 16, NJB, NIB);
+        CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<3>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
+                            mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, skipI, skipJ, wst);
     }
     CASMTR_CHECK_LAUNCH();
     return 0;

@@ -75,7 +75,8 @@ static const char* kNames[CASMTR_PROF_COUNT] = {
     "dual_softmax_gemm", "dual_softmax_reduce", "dual_softmax_pass2", "dual_softmax_select", "qta_coarsest[logits]", "qta_coarsest[row]",
     "qta_coarsest[av]", "qta_fine_level[lists<=64]", "cascade_attn", "window_match", "nms_select",
     "layout", "window_warp_idx", "linear_nt", "token_pool", "qta_coarsest_level",
-    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "dual_softmax_split_prepass", "dual_softmax_fix"};
+    "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "dual_softmax_split_prepass", "dual_softmax_fix",
+    "dual_softmax_gemm_edge"};
 
 static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {

@@ -131,6 +131,43 @@ def test_split_full_size_vs_exact(ops):
         assert float((sp["mconf"][:n] - ex["mconf"][:n]).abs().max()) < 1e-6 if n else True
 
 
+@pytest.mark.parametrize("hw0,hw1", [((40, 36), (28, 40)), ((16, 16), (24, 24)), ((52, 52), (52, 52))])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("knob", ["CASMTR_DS_GEMM16_WIDE", "CASMTR_DS_GEMM16_WST"])
+def test_gemm16_variants_are_bit_identical(ops, monkeypatch, hw0, hw1, masked, knob):
+    """Measurement variants of the split GEMM against the shipped ds_gemm16_kernel, every output bit for bit:
+    CASMTR_DS_GEMM16_WIDE=1: ds_gemm16w_kernel (128 x 64 wave tiles over the whole 256 x 128 blocks, the strips by ds_gemm16_kernel;
+    every accumulator sees the same MFMA sequence and the same epilogue); CASMTR_DS_GEMM16_WST=1: the similarity matrix stored from the
+    epilogue's LDS slabs in 1 KB instructions instead of 256-byte ones from the accumulator layout.
+    1440 x 1120 (5 whole blocks + a 160-row strip; 8 column tiles + a 96-column strip), 256 x 576 (one block row, no row strip),
+    2704 x 2704."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, C = 2, 256
+    L, S = hw0[0] * hw0[1], hw1[0] * hw1[1]
+    f0 = torch.randn((B, L, C), generator=g).to(DEV)
+    f1 = torch.randn((B, S, C), generator=g).to(DEV)
+    m0 = m1 = valid = None
+    if masked:
+        a = torch.ones((B,) + hw0, dtype=torch.bool)
+        c = torch.ones((B,) + hw1, dtype=torch.bool)
+        a[:, hw0[0] - 5:], a[:, :, hw0[1] - 3:] = False, False
+        c[:, hw1[0] - 2:], c[:, :, hw1[1] - 7:] = False, False
+        m0, m1 = a.reshape(B, -1).to(DEV), c.reshape(B, -1).to(DEV)
+        valid = torch.tensor([[hw0[0] - 5, hw0[1] - 3, hw1[0] - 2, hw1[1] - 7]] * B, dtype=torch.int32, device=DEV)
+    for want_conf in (False, True):
+        run = lambda: ops.dual_softmax(f0, f1, hw0, hw1, 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, want_conf=want_conf, gemm="split")
+        monkeypatch.delenv(knob, raising=False)
+        ref = run()
+        monkeypatch.setenv(knob, "1")
+        out = run()
+        n = int(ref["n"].item())
+        assert int(out["n"].item()) == n
+        for k in ("conf_matrix" if want_conf else "sim", "next_idx_c01", "next_idx_c10", "next_conf_c01", "next_conf_c10"):
+            assert torch.equal(out[k], ref[k]), k
+        for k in ("i_ids", "j_ids", "b_ids", "mconf"):
+            assert torch.equal(out[k][:n], ref[k][:n]), k
+
+
 def test_split_low_threshold_uses_dense_pass(ops):
     """thr < 1e-3: the sparse pass 2 (whose segment test needs log(thr * rsum)) hands over to the dense one; same lists as the exact path"""
     g = torch.Generator(device="cpu").manual_seed(9)
