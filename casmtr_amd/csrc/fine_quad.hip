@@ -56,7 +56,7 @@ struct FineQArgs {
     float temp, w_level;
     int topk, B, h0, w0, h1, w1, H, Kp, nquads, lq1;
     unsigned div_magic;      // ceil(2^32 / (w1/2)): p / (w1/2) == umulhi(p, div_magic) for p < 2^22 (0: w1/2 == 1)
-    int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores, 8 one K/V slice for all pairs
+    int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores, 8 one K/V slice for all pairs, 16 staggered start
 };
 
 __device__ __forceinline__ void ce_desc(unsigned& a, unsigned& b) {   // compare-exchange: a >= b afterwards
@@ -311,6 +311,10 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
         }
         return true;
     };
+    if (a.xflags & 16) {   // timing experiment: the waves of a CU start up to one item period apart
+        const int k = ((int)(blockIdx.x >> 3) % 5) * 2 + wave;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(11);
+    }
     const unsigned stg_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(stg));
     // The item's whole front end arrives by ONE global_load_lds_dwordx4 (round 5; four global_load_lds_dword before: an LDS-DMA
     // wave-instruction costs the CU's texture-address path ~19 cycles whatever its width, tools/probes/dma_width.hip, so the four narrow
