@@ -300,14 +300,16 @@ __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* sc
 #define DS16_LDS (4 * 32 * 65 * 4 + 2 * 2 * 128 * 3 * 4 + 2 * 128 * 4)   // epilogue scratch (aliases the stages; the interior-tile
                                                                           // layout 4*32*68 + 2*2*128*2 floats is 512 B smaller) + factors
 #define DS16_LDS3 (3 * DS16_STAGE + 2 * 128 * 4)                          // three operand stages (prefetch distance 2) + factors
-template <int NSTG>   // operand stages in LDS: 2 (prefetch distance 1, 40 KB) or 3 (distance 2, 49 KB; still 3 workgroups per CU)
+template <int NSTG>   // operand stages in LDS: 2 (prefetch distance 1, 40 KB) or 3 (distance 2, 49 KB; still 3 workgroups per CU);
+                      // 4 = three stages + the NEXT stage's fragments read into registers under the current stage's MFMAs
 __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
                                                            float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB, int skipI, int skipJ, int wst) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
     char* lds = reinterpret_cast<char*>(smem);
-    float* facA = smem + ((NSTG == 3 ? DS16_LDS3 : DS16_LDS) - 2 * 128 * 4) / 4;
+    constexpr bool PF = NSTG == 4;
+    float* facA = smem + ((NSTG >= 3 ? DS16_LDS3 : DS16_LDS) - 2 * 128 * 4) / 4;
     float* facB = facA + 128;
     const int NSJ = (NJB + 7) >> 3;
     const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
@@ -345,14 +347,74 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     const int any_masked = __syncthreads_or(masked);   // (barrier: the factor loads above have completed before any DMA is outstanding)
     glds_2k(a_src, voff, lds0);
     glds_2k(b_src, voff, lds0 + 8192);
-    if (NSTG == 3 && KS > 1) {
+    if (NSTG >= 3 && KS > 1) {
         glds_2k(a_src + 8192, voff, lds0 + DS16_STAGE);
         glds_2k(b_src + 8192, voff, lds0 + DS16_STAGE + 8192);
+    }
+    if (PF && KS > 2) {
+        glds_2k(a_src + 2 * 8192, voff, lds0 + 2 * DS16_STAGE);
+        glds_2k(b_src + 2 * 8192, voff, lds0 + 2 * DS16_STAGE + 8192);
     }
     const int hi = lane >> 5, ln = lane & 31;
     // fragment (ti, part): plane (kg = hi, part), row wr*64 + ti*32 + ln
     const char* fa_base = lds + (hi * 2) * 2048 + (wr * 64 + ln) * 16;
     const char* fb_base = lds + 8192 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
+    if constexpr (PF) {
+        // Stage ks is consumed from registers while stage ks + 1 is read from LDS, stage ks + 2 is landing and stage ks + 3 is issued
+        // into the buffer stage ks was read from (everyone has read it: those reads were completed before this iteration's barrier).
+        struct Frag { h16x8 ah[2], al[2], bh[2], bl[2]; };
+        auto read = [&](Frag& f, int bufi) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const char* pa = fa_base + bufi * DS16_STAGE + ti * 512;
+                const char* pb = fb_base + bufi * DS16_STAGE + ti * 512;
+                f.ah[ti] = *reinterpret_cast<const h16x8*>(pa);
+                f.al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
+                f.bh[ti] = *reinterpret_cast<const h16x8*>(pb);
+                f.bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
+            }
+        };
+        auto mfmas = [&](const Frag& f) {   // small terms first; every accumulator is touched again only after three other MFMAs
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ti], f.bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
+        };
+        int bcur = 0;   // buffer of stage ks
+        auto step = [&](int ks, const Frag& cur, Frag& nxt) {
+            const int bn = bcur == 2 ? 0 : bcur + 1;   // buffer of stage ks + 1
+            if (ks + 1 < KS) {
+                if (ks + 2 < KS) glds_wait<4>(); else glds_wait<0>();   // stage ks + 1 has landed when only stage ks + 2 is in flight
+                lds_reads_done();
+                __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave has read stage ks out of buffer bcur
+                asm volatile("" ::: "memory");
+                if (ks + 3 < KS) {
+                    glds_2k(a_src + (size_t)(ks + 3) * 8192, voff, lds0 + (unsigned)(bcur * DS16_STAGE));
+                    glds_2k(b_src + (size_t)(ks + 3) * 8192, voff, lds0 + (unsigned)(bcur * DS16_STAGE) + 8192);
+                }
+                read(nxt, bn);
+            }
+            mfmas(cur);
+            bcur = bn;
+        };
+        Frag f0, f1;
+        if (KS > 2) glds_wait<8>(); else if (KS > 1) glds_wait<4>(); else glds_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read(f0, 0);
+        for (int ks = 0; ks < KS; ks += 2) {
+            step(ks, f0, f1);
+            if (ks + 1 < KS) step(ks + 1, f1, f0);
+        }
+    } else {
     int buf = 0;
     for (int ks = 0; ks < KS; ++ks) {
         if (NSTG == 3) {
@@ -399,6 +461,7 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
         buf = NSTG == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
+    }
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
     if (tI * DS_BM + DS_BM <= L && tJ * DS_BN + DS_BN <= S) {
@@ -567,7 +630,12 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
         if (skipI >= NIB && skipJ >= NJB) { CASMTR_CHECK_LAUNCH(); return 0; }
     }
     const char* ev3 = getenv("CASMTR_DS_GEMM16_STAGES");
-    if (ev3 && ev3[0] == '2') {
+    if (ev3 && ev3[0] == '4') {
+        const size_t lds = DS16_LDS3;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<4>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
+                            mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, skipI, skipJ, wst);
+    } else if (ev3 && ev3[0] == '2') {
         const size_t lds = DS16_LDS;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,

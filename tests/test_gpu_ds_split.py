@@ -133,12 +133,13 @@ def test_split_full_size_vs_exact(ops):
 
 @pytest.mark.parametrize("hw0,hw1", [((40, 36), (28, 40)), ((16, 16), (24, 24)), ((52, 52), (52, 52))])
 @pytest.mark.parametrize("masked", [False, True])
-@pytest.mark.parametrize("knob", ["CASMTR_DS_GEMM16_WIDE", "CASMTR_DS_GEMM16_WST"])
+@pytest.mark.parametrize("knob", ["CASMTR_DS_GEMM16_WIDE=1", "CASMTR_DS_GEMM16_WST=1", "CASMTR_DS_GEMM16_STAGES=4", "CASMTR_DS_GEMM16_STAGES=3"])
 def test_gemm16_variants_are_bit_identical(ops, monkeypatch, hw0, hw1, masked, knob):
     """Measurement variants of the split GEMM against the shipped ds_gemm16_kernel, every output bit for bit:
     CASMTR_DS_GEMM16_WIDE=1: ds_gemm16w_kernel (128 x 64 wave tiles over the whole 256 x 128 blocks, the strips by ds_gemm16_kernel;
     every accumulator sees the same MFMA sequence and the same epilogue); CASMTR_DS_GEMM16_WST=1: the similarity matrix stored from the
-    epilogue's LDS slabs in 1 KB instructions instead of 256-byte ones from the accumulator layout.
+    epilogue's LDS slabs in 1 KB instructions instead of 256-byte ones from the accumulator layout; CASMTR_DS_GEMM16_STAGES=2 | 3 | 4:
+    operand ring of two or three stages, 4 = three stages + the next stage's fragments read into registers under the MFMAs.
     1440 x 1120 (5 whole blocks + a 160-row strip; 8 column tiles + a 96-column strip), 256 x 576 (one block row, no row strip),
     2704 x 2704."""
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -156,9 +157,13 @@ def test_gemm16_variants_are_bit_identical(ops, monkeypatch, hw0, hw1, masked, k
         valid = torch.tensor([[hw0[0] - 5, hw0[1] - 3, hw1[0] - 2, hw1[1] - 7]] * B, dtype=torch.int32, device=DEV)
     for want_conf in (False, True):
         run = lambda: ops.dual_softmax(f0, f1, hw0, hw1, 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, want_conf=want_conf, gemm="split")
-        monkeypatch.delenv(knob, raising=False)
+        name, val = knob.split("=")
+        if name == "CASMTR_DS_GEMM16_STAGES":
+            monkeypatch.setenv(name, "2")   # the two-stage form as the reference for the ring variants
+        else:
+            monkeypatch.delenv(name, raising=False)
         ref = run()
-        monkeypatch.setenv(knob, "1")
+        monkeypatch.setenv(name, val)
         out = run()
         n = int(ref["n"].item())
         assert int(out["n"].item()) == n

@@ -36,6 +36,11 @@ print("64 x 64 wave tiles:", scopes(), flush=True)
 os.environ["CASMTR_DS_GEMM16_WST"] = "1"
 print("64 x 64 wave tiles, 1 KB stores from the slabs:", scopes(), flush=True)
 os.environ.pop("CASMTR_DS_GEMM16_WST")
+for rep in range(2):
+    for st in ("3", "4"):
+        os.environ["CASMTR_DS_GEMM16_STAGES"] = st
+        print(f"64 x 64 wave tiles, CASMTR_DS_GEMM16_STAGES={st}:", scopes(), flush=True)
+os.environ.pop("CASMTR_DS_GEMM16_STAGES")
 os.environ["CASMTR_DS_GEMM16_WIDE"] = "1"
 print("128 x 64 wave tiles + strips:", scopes(), flush=True)
 for flags, name in ((4096, "no epilogue"), (8192, "no MFMAs"), (4096 + 8192, "DMA + LDS reads only")):
