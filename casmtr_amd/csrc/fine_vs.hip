@@ -330,6 +330,8 @@ int casmtr_qta_fine_level_vs(const float* q, const float* key, const float* valu
     else if (abl == 32) VS_GO(4, 32);
     else if (abl == 64) VS_GO(0, 64);
     else if (abl == 126) VS_GO(0, 126);
+    else if (abl == 46) VS_GO(4, 46);
+    else if (abl == 80) VS_GO(0, 80);
     else if (nst == 4) VS_GO(4, 0);
     else if (nst == 2) VS_GO(2, 0);
     else VS_GO(0, 0);
