@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void fine_vs_kernel(const FineVsArgs a) {
         for (int j = 0; j < 8; ++j) { if constexpr (ABL & 16) kreg[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; else VS_LOAD(kreg[j], voff[j], base); }
     };
     auto load_v = [&](int b) {
-        const float* base = uniform_base(v0, b);
+        const float* base = uniform_base((ABL & 128) ? k0 : v0, b);   // (128: timing experiment, the V rows come from the K slice: half the L2 working set)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { if constexpr (ABL & 16) vreg[j] = (f32x4){1.f, 0.f, 0.f, 0.f}; else VS_LOAD(vreg[j], voff[j], base); }
     };
@@ -331,6 +331,7 @@ int casmtr_qta_fine_level_vs(const float* q, const float* key, const float* valu
     else if (abl == 64) VS_GO(0, 64);
     else if (abl == 126) VS_GO(0, 126);
     else if (abl == 46) VS_GO(4, 46);
+    else if (abl == 128) VS_GO(4, 128);
     else if (abl == 80) VS_GO(0, 80);
     else if (nst == 4) VS_GO(4, 0);
     else if (nst == 2) VS_GO(2, 0);

@@ -39,7 +39,8 @@ print(f"fine_quad_kernel<1,false,true>: {timeit():.1f} us per launch", flush=Tru
 os.environ["CASMTR_FQ_VARIANT"] = "vs"
 NAMES = {0: "everything", 2: "no softmax", 4: "no V pass (1 of 32 reads and MFMAs)", 8: "no K pass (1 of 16 reads, 4 of 32 MFMAs)", 16: "no row loads",
          32: "no row writes to LDS (2 of 16)", 64: "no output stores", 126: "none of these (loop, staging, waits)",
-         46: "memory only: row loads + stores (no softmax, passes, row writes)", 80: "compute only: no row loads, no stores"}
+         46: "memory only: row loads + stores (no softmax, passes, row writes)", 80: "compute only: no row loads, no stores",
+         128: "V rows read from the K slice (same accesses, half the L2 working set)"}
 for blocks in (512, 768):
     os.environ["CASMTR_VS_BLOCKS"] = str(blocks)
     for abl, name in NAMES.items():
