@@ -41,8 +41,11 @@ NAMES = {0: "everything", 2: "no softmax", 4: "no V pass (1 of 32 reads and MFMA
          32: "no row writes to LDS (2 of 16)", 64: "no output stores", 126: "none of these (loop, staging, waits)",
          46: "memory only: row loads + stores (no softmax, passes, row writes)", 80: "compute only: no row loads, no stores",
          128: "V rows read from the K slice (same accesses, half the L2 working set)"}
-for blocks in (512, 768):
+only = [int(x) for x in os.environ.get("FQ_ABL_LIST", "").split(",") if x]   # e.g. FQ_ABL_LIST=0,128 under rocprofv3 --pmc
+for blocks in ((512,) if only else (512, 768)):
     os.environ["CASMTR_VS_BLOCKS"] = str(blocks)
     for abl, name in NAMES.items():
+        if only and abl not in only:
+            continue
         os.environ["CASMTR_VS_ABLATE"] = str(abl)
         print(f"fine_vs_kernel, {blocks // 64} waves per CU, {name}: {timeit():.1f} us per launch", flush=True)
