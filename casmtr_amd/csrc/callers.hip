@@ -22,6 +22,11 @@ struct LinearBatch {
     const float* w[LIN_MAXP];
     const float* bias[LIN_MAXP];  // nullable
     float* y[LIN_MAXP];
+    // quad-major output (casmtr_linear_quads_fwd): rows are the tokens of qh x qw grids, y = [M/(qh*qw)][N/32][(qh/2)*(qw/2)][4][32]
+    // (the layout of quad_layout.hip); qw == 0: plain [M][N].  Division of the in-grid position by qw via m = ceil(2^32 / qw),
+    // n / qw = umulhi(n, m), exact for n * (m * qw - 2^32) < 2^32 (checked on the host)
+    int qh, qw;
+    unsigned magic_w;
 };
 
 // 128x128 block tile, 4 waves x (64x64), v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain), BK = 32 with the next
@@ -86,6 +91,37 @@ __global__ __launch_bounds__(256, 3) void linear_nt_kernel(const LinearBatch lb,
     const int hi = lane >> 5, ln = lane & 31;
     const float* __restrict__ bias = lb.bias[p];
     float* __restrict__ Y = lb.y[p];
+    if (lb.qw) {
+        // quad-major: a 32-column block is one head's 32 dims = the 128 contiguous bytes of a (quad, child) row; only the row offset
+        // differs from the token-major store
+        const int hw = lb.qh * lb.qw, wq = lb.qw >> 1, Lq = (lb.qh >> 1) * wq, Hh = N >> 5;
+        const unsigned b0 = (unsigned)i0 / (unsigned)hw, rem0 = (unsigned)i0 - b0 * (unsigned)hw;   // wave-uniform
+        float bj[2];
+        float* yh[2];
+        bool okj[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int gj = j0 + wc * 64 + tj * 32 + ln;
+            okj[tj] = gj < N;
+            bj[tj] = bias && okj[tj] ? bias[gj] : 0.f;
+            yh[tj] = Y + (size_t)(gj >> 5) * Lq * 128 + ln;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned gi = (unsigned)(i0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                if ((int)gi >= M) continue;
+                unsigned b = b0, pp = rem0 + (gi - (unsigned)i0);   // the tile's 128 rows start in pair b0 and rarely leave it
+                while (pp >= (unsigned)hw) { pp -= (unsigned)hw; ++b; }
+                const unsigned y = __umulhi(pp, lb.magic_w), x = pp - y * (unsigned)lb.qw;
+                const size_t roff = ((size_t)b * Hh * Lq + (size_t)((y >> 1) * wq + (x >> 1))) * 128 + ((y & 1) * 2 + (x & 1)) * 32;
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    if (okj[tj]) yh[tj][roff] = bias ? acc[ti][tj][r] + bj[tj] : acc[ti][tj][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         const int gj = j0 + wc * 64 + tj * 32 + ln;
@@ -101,11 +137,26 @@ __global__ __launch_bounds__(256, 3) void linear_nt_kernel(const LinearBatch lb,
     }
 }
 
-extern "C" int casmtr_linear_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
-                                 int nprob, int M, int N, int K, casmtr_stream_t stream) {
+static bool lin_magic(unsigned d, unsigned nmax, unsigned* m) {   // n / d == umulhi(n, m) for every n <= nmax ?
+    if (d == 0) return false;
+    if (d < 2) return false;
+    const unsigned long long mm = (0x100000000ull + d - 1) / d;
+    const unsigned long long e = mm * d - 0x100000000ull;
+    if ((unsigned long long)nmax * e >= 0x100000000ull) return false;
+    *m = (unsigned)mm;
+    return true;
+}
+
+static int linear_launch(const float* const* x, const float* const* w, const float* const* bias, float* const* y, int nprob, int M, int N,
+                         int K, int qh, int qw, casmtr_stream_t stream) {
     if (nprob <= 0 || M <= 0 || N <= 0) return 0;
     if (nprob > LIN_MAXP || K <= 0 || K % LIN_BK != 0) return CASMTR_ERR_UNSUPPORTED;
     LinearBatch lb{};
+    if (qw) {
+        if (qh <= 0 || qw <= 1 || (qh & 1) || (qw & 1) || (N & 31) || M % (qh * qw) != 0) return CASMTR_ERR_UNSUPPORTED;
+        if (!lin_magic((unsigned)qw, (unsigned)(qh * qw), &lb.magic_w)) return CASMTR_ERR_UNSUPPORTED;
+        lb.qh = qh; lb.qw = qw;
+    }
     for (int i = 0; i < nprob; ++i) {
         lb.x[i] = x[i]; lb.w[i] = w[i]; lb.bias[i] = bias ? bias[i] : nullptr; lb.y[i] = y[i];
     }
@@ -113,6 +164,20 @@ extern "C" int casmtr_linear_fwd(const float* const* x, const float* const* w, c
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_LINEAR, linear_nt_kernel, dim3(NIB * NJB, nprob), dim3(256), 0, (hipStream_t)stream, lb, M, N, K, NJB);
     CASMTR_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int casmtr_linear_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
+                                 int nprob, int M, int N, int K, casmtr_stream_t stream) {
+    return linear_launch(x, w, bias, y, nprob, M, N, K, 0, 0, stream);
+}
+
+// The same projections with the result written quad-major per head, [B][N/32][(h/2)*(w/2)][4][32] (M = B*h*w token rows of h x w
+// grids): what the fine-level / cascade kernels read (fine_quad.hip, cascade_quad.hip), so that the token -> quad layout pass
+// (casmtr_tokens_to_quads) between the projection and the attention disappears.  Same arithmetic, same values.
+extern "C" int casmtr_linear_quads_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
+                                       int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream) {
+    if (h <= 0 || w_ <= 0) return CASMTR_ERR_UNSUPPORTED;
+    return linear_launch(x, w, bias, y, nprob, M, N, K, h, w_, stream);
 }
 
 // =================================================================================================== token pyramid
@@ -152,6 +217,49 @@ extern "C" int casmtr_token_pool_fwd(const float* const* src, float* const* dst,
     ProfScope ps(CASMTR_PROF_TOKEN_POOL, (hipStream_t)stream, "token_pool_kernel");
     hipLaunchKernelGGL(token_pool_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, pb,
                        H, W, C / 4, total);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// =================================================================================================== pyramid on quad-major tensors
+// F.avg_pool2d(kernel 2, stride 2) of a quad-major level: the 2x2 window of pooled token (Y, X) IS quad (Y, X)'s four children, in the
+// (row, col) order of torch's accumulation: pooled = (((c0 + c1) + c2) + c3) * 0.25, one 128-byte row per head.  The pooled level is
+// written quad-major again ([B][H][(h/4)*(w/4)][4][32], for the next finer level's kernels) or token-major ([B][(h/2)*(w/2)][C], what
+// the coarsest level's kernel reads).  Lane <-> (quad l / 8, 16-byte unit l % 8): four 128-byte pieces per load instruction and quad,
+// 128-byte rows out.
+__global__ __launch_bounds__(256) void quad_pool_kernel(const PoolBatch pb, int Hh, int hq, int wq, int to_tokens, long long total) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, head, quad, unit)
+    if (g >= total) return;
+    const int u = (int)(g & 7);
+    long long t = g >> 3;
+    const int Lq = hq * wq;
+    const int quad = (int)(t % Lq); t /= Lq;
+    const int hd = (int)(t % Hh);
+    const int b = (int)(t / Hh);
+    const f32x4* s = reinterpret_cast<const f32x4*>(pb.src[blockIdx.y]) + ((size_t)(b * Hh + hd) * Lq + quad) * 32 + u;
+    const f32x4 a = s[0], bb = s[8], c = s[16], d = s[24];
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (((a[i] + bb[i]) + c[i]) + d[i]) * 0.25f;
+    const int Y = quad / wq, X = quad - Y * wq;
+    size_t off;   // in 16-byte units
+    if (to_tokens) off = ((size_t)b * Lq + quad) * (Hh * 8) + hd * 8 + u;
+    else off = (((size_t)(b * Hh + hd) * ((hq >> 1) * (wq >> 1)) + (Y >> 1) * (wq >> 1) + (X >> 1)) * 4 + (Y & 1) * 2 + (X & 1)) * 8 + u;
+    reinterpret_cast<f32x4*>(pb.dst[blockIdx.y])[off] = o;
+}
+
+// src: n quad-major tensors of B x (h x w tokens) x C; dst: the pooled (h/2 x w/2) levels, quad-major or (to_tokens) token-major
+extern "C" int casmtr_quad_pool_fwd(const float* const* src, float* const* dst, int n, int B, int h, int w, int C, int to_tokens,
+                                    casmtr_stream_t stream) {
+    if (n <= 0 || B <= 0) return 0;
+    if (n > POOL_MAXT || (C & 31) || h < 2 || w < 2 || (h & 1) || (w & 1) || (!to_tokens && ((h & 3) || (w & 3)))) return CASMTR_ERR_UNSUPPORTED;
+    PoolBatch pb{};
+    for (int i = 0; i < n; ++i) { pb.src[i] = src[i]; pb.dst[i] = dst[i]; }
+    const long long total = (long long)B * (C / 32) * (h / 2) * (w / 2) * 8;
+    ProfScope ps(CASMTR_PROF_TOKEN_POOL, (hipStream_t)stream, "quad_pool_kernel");
+    hipLaunchKernelGGL(quad_pool_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, pb, C / 32, h / 2, w / 2,
+                       to_tokens, total);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }

@@ -207,6 +207,11 @@ class QTAttB(nn.Module):
             for t in list(out.values()) + [q0, k0, v0]:   # allocated on the side stream, consumed (and later freed) on this one
                 if torch.is_tensor(t):
                     t.record_stream(torch.cuda.current_stream())
+        return self._finer_levels_quad(out, quads, hw_q, hw_k, weight, want_topk)
+
+    def _finer_levels_quad(self, out, quads, hw_q, hw_k, weight, want_topk=False):
+        """levels 1 .. n-1 on quad-major operands (quads: q, k, v per level, coarser first), `out` the coarsest level's result"""
+        n = len(hw_q)
         acc, tab = out["acc"], out["topk_tab"]
         per_level = [out]
         for i in range(1, n):
@@ -218,6 +223,23 @@ class QTAttB(nn.Module):
             per_level.append(out)
         self._last_levels = per_level if want_topk else None
         return acc
+
+    def quads_ok(self, hw_q, hw_k):
+        """hw_q / hw_k finest first: can forward_quads run these shapes on the quad-major kernels?"""
+        return self._quad_major_ok(list(reversed(hw_q)), list(reversed(hw_k)))
+
+    def forward_quads(self, coarsest, finer, hw_q, hw_k):
+        """Entry point for producers that write the operand layouts themselves (casmtr_amd.modules.quadtree_block: the projections
+        through ops.linear_quads_multi, the pyramid through ops.quad_pool_multi -- no layout pass): coarsest = (q, k, v) token-major
+        [N, h*w, C] of the coarsest level, finer = [(q, k, v)] quad-major [N, H, (h/2)*(w/2), 4, 32] per finer level, FINEST first;
+        hw_q / hw_k finest first -> message [N, H*W, nhead, dim].  Inference only."""
+        if self.lepe or _needs_autograd(self.weight):
+            raise RuntimeError("QTAttB.forward_quads is the inference path (no lepe, no autograd): use forward()")
+        hq, hk = list(reversed(hw_q)), list(reversed(hw_k))
+        weight = self._level_weights()
+        out = ops.qta_coarse_level(*coarsest, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=False)
+        quads = [t for lvl in reversed(finer) for t in lvl]
+        return self._finer_levels_quad(out, quads, hq, hk, weight)
 
     def forward_multi(self, calls, split_fine=False):
         """calls: list of (queries, keys, values) pyramid triples of identical shapes whose results do not depend on each other -- the two
@@ -493,6 +515,17 @@ class CascadeQTAttB(nn.Module):
         tp = torch.cat([c[3].contiguous() for c in calls], 0)
         msg = ops.cascade_attn_quad(qm[0], qm[1], qm[2], tp, hw_q, hw_k, self.nhead, None)
         return [msg[g * B:(g + 1) * B] for g in range(len(calls))]
+
+    def quads_ok(self, hw_q, hw_k, kw):
+        import os
+        return (os.environ.get("CASMTR_CASCADE_KERNEL", "qm") == "qm"
+                and ops.cascade_quad_supported(self.nhead, self.dim, tuple(hw_q), tuple(hw_k), kw, self.dilated))
+
+    def forward_quads(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None):
+        """Quad-major entry point (operands [N, H, (h/2)*(w/2), 4, 32] written by the projections themselves,
+        ops.linear_quads_multi): message only, no index output.  Inference only."""
+        rp = None if rel_pos is None else rel_pos.contiguous().float()
+        return ops.cascade_attn_quad(q, k, v, topk_pos.contiguous(), tuple(hw_q), tuple(hw_k), self.nhead, rp)
 
     def forward_tokens(self, q, k, v, hw_q, hw_k, topk_pos, rel_pos=None, want_idx=True):
         """Token-major entry point: q [N,h0*w0,C], k/v [N,h1*w1,C].  Inference only."""

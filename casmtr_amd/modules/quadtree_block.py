@@ -50,6 +50,24 @@ def _project_qkv(mod, x, target):
     return q, k, v
 
 
+def _project_qkv_quads(mod, x, target, hw, hw1):
+    """the same projections written quad-major per head by the GEMM itself (ops.linear_quads_multi): no token -> quad layout pass"""
+    ws = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
+    bs = [mod.q_proj.bias, mod.k_proj.bias, mod.v_proj.bias]
+    ws = [w.detach().float() for w in ws]
+    bs = [None if b is None else b.detach().float() for b in bs]
+    if x.shape == target.shape and tuple(hw) == tuple(hw1):
+        return ops.linear_quads_multi([x, target, target], ws, bs, *hw)
+    (q,) = ops.linear_quads_multi([x], ws[:1], bs[:1], *hw)
+    k, v = ops.linear_quads_multi([target, target], ws[1:], bs[1:], *hw1)
+    return q, k, v
+
+
+def _quad_route():
+    import os
+    return os.environ.get("CASMTR_CALLER_LAYOUT", "quads") == "quads"   # "tokens": the round-2 token-major route (tests compare the two)
+
+
 class QuadtreeAttention(nn.Module):
     def __init__(self, dim, num_heads, topks, value_branch=False, act=nn.GELU(), qkv_bias=False, qk_scale=None,
                  attn_drop=0.0, proj_drop=0.0, scale=1, attn_type="B"):
@@ -84,6 +102,25 @@ class QuadtreeAttention(nn.Module):
         B, N, C = x.shape
         if not self._fused_ok(x, target, rel_pos):
             return self._forward_reference_structure(x, target, H, W, H1, W1, rel_pos, topk_pos)
+        hw_q = [(H >> i, W >> i) for i in range(self.scale)]
+        hw_k = [(H1 >> i, W1 >> i) for i in range(self.scale)]
+        if (_quad_route() and self.scale > 1 and C % 32 == 0 and all(h % 2 == 0 and w % 2 == 0 for h, w in hw_q[:-1] + hw_k[:-1])
+                and self.py_att.quads_ok(hw_q, hw_k)):
+            # projections straight into the fine-level kernels' quad-major layout, pyramid on quad-major levels, the coarsest level
+            # pooled into the token-major layout its kernel reads: no layout pass anywhere (round 5)
+            q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
+            finer = []
+            for i in range(self.scale - 1):
+                finer.append((q, k, v))
+                last = i == self.scale - 2
+                if hw_q[i] == hw_k[i]:
+                    q, k, v = ops.quad_pool_multi([q, k, v], *hw_q[i], to_tokens=last)
+                else:
+                    (q,), (k, v) = ops.quad_pool_multi([q], *hw_q[i], to_tokens=last), ops.quad_pool_multi([k, v], *hw_k[i], to_tokens=last)
+            msg = self.py_att.forward_quads((q, k, v), finer, hw_q, hw_k).view(B, -1, C)
+            out = ops.linear(msg, self.proj.weight.detach().float(),
+                             None if self.proj.bias is None else self.proj.bias.detach().float())
+            return self.proj_drop(out)
         q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
         queries, keys, values, hw_q, hw_k = [], [], [], [], []
         h, w, h1, w1 = H, W, H1, W1
@@ -145,6 +182,13 @@ class CascadeQuadtreeAttention(nn.Module):
         if rel_pos is not None:
             rel_pos = rel_pos.to(torch.float32)
         if x.is_cuda and not _needs_autograd(x, target, rel_pos, *self.parameters()):
+            if (not want_idx and _quad_route() and C % 32 == 0 and H % 2 == 0 and W % 2 == 0 and H1 % 2 == 0 and W1 % 2 == 0
+                    and self.cross_attn.quads_ok((H, W), (H1, W1), idx.shape[2])):
+                q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
+                msg = self.cross_attn.forward_quads(q, k, v, (H, W), (H1, W1), idx, rel_pos)
+                out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
+                                 None if self.proj.bias is None else self.proj.bias.detach().float())
+                return self.proj_drop(out), None
             q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
             msg, upsampled_idx = self.cross_attn.forward_tokens(q, k, v, (H, W), (H1, W1), idx, rel_pos, want_idx)
             out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),

@@ -186,6 +186,44 @@ def linear(x, w, bias=None):
     return linear_multi([x], [w], [bias])[0]
 
 
+def linear_quads_multi(xs, ws, biases, h, w):
+    """linear_multi with the results written quad-major per head: x_i [B, h*w, K] -> [B, N/32, (h/2)*(w/2), 4, 32] (the layout
+    tokens_to_quads produces), one launch, no layout pass.  h, w even, N % 32 == 0."""
+    import ctypes as C
+    n = len(xs)
+    biases = [None] * n if biases is None else list(biases)
+    xs = [_chk(x, "x") for x in xs]
+    ws = [_chk(wt.reshape(wt.shape[0], -1), "w") for wt in ws]
+    bs = [_chk(b, "bias") for b in biases]
+    N, K = ws[0].shape
+    B = xs[0].shape[0]
+    M = B * h * w
+    if any(tuple(x.shape) != (B, h * w, K) for x in xs) or any(tuple(wt.shape) != (N, K) for wt in ws):
+        raise RuntimeError("linear_quads_multi: x_i must be [B, h*w, K] and all problems share (N, K)")
+    ys = [torch.empty((B, N // 32, (h // 2) * (w // 2), 4, 32), device=x.device, dtype=torch.float32) for x in xs]
+    arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    with torch.cuda.device(xs[0].device):
+        _lib.check(_lib.lib().casmtr_linear_quads_fwd(arr(xs), arr(ws), arr(bs), arr(ys), n, M, N, K, h, w, _stream()), "linear_quads_fwd")
+    return ys
+
+
+def quad_pool_multi(xs, h, w, to_tokens=False):
+    """avg_pool2d(2, 2) on quad-major tensors [B, H, (h/2)*(w/2), 4, 32] (h x w tokens) -> the pooled level quad-major
+    [B, H, (h/4)*(w/4), 4, 32], or token-major [B, (h/2)*(w/2), H*32] with to_tokens; one launch."""
+    import ctypes as C
+    n = len(xs)
+    xs = [_chk(x, "x") for x in xs]
+    B, H = xs[0].shape[:2]
+    if any(tuple(x.shape) != (B, H, (h // 2) * (w // 2), 4, 32) for x in xs):
+        raise RuntimeError("quad_pool_multi: tensors must be quad-major [B, H, (h/2)*(w/2), 4, 32]")
+    shape = (B, (h // 2) * (w // 2), H * 32) if to_tokens else (B, H, (h // 4) * (w // 4), 4, 32)
+    ys = [torch.empty(shape, device=x.device, dtype=torch.float32) for x in xs]
+    arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    with torch.cuda.device(xs[0].device):
+        _lib.check(_lib.lib().casmtr_quad_pool_fwd(arr(xs), arr(ys), n, B, h, w, H * 32, int(bool(to_tokens)), _stream()), "quad_pool_fwd")
+    return ys
+
+
 def token_pool_multi(xs, H, W):
     """avg_pool2d(2, 2) on token-major tensors: list of [B,H*W,C] -> list of [B,(H//2)*(W//2),C], one launch."""
     import ctypes as C

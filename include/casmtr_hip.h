@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 5
+#define CASMTR_ABI_VERSION 6
 int casmtr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -223,6 +223,20 @@ size_t casmtr_nms_select_ws_bytes(int B, int H0, int W0);
  * x/w/bias/y are HOST arrays of device pointers; bias (or any bias[p]) may be NULL.  K % 32 == 0.                */
 int casmtr_linear_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
                       int nprob, int M, int N, int K, casmtr_stream_t stream);
+
+/* The same projections with y_p written quad-major per head, [B][N/32][(h/2)*(w/2)][4][32] (the M = B*h*w rows of x_p are the
+ * tokens of h x w grids, row-major): the operand layout of casmtr_qta_fine_level_quad_fwd / casmtr_cascade_attn_quad_fwd, i.e. the
+ * reference's "b c (h t1) (w t2) -> b (h w) (t1 t2) c" (cuda_imp/.../modules/quadtree_attention.py:188-189) applied by the producer.
+ * Same arithmetic and values as casmtr_linear_fwd followed by casmtr_tokens_to_quads.  h, w even, N % 32 == 0.  (round 5)      */
+int casmtr_linear_quads_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
+                            int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream);
+
+/* F.avg_pool2d(kernel_size=2, stride=2) of the pyramid loop (quadtree_attention.py:82-90) on QUAD-major tensors: src_i
+ * [B][C/32][(h/2)*(w/2)][4][32] (h x w tokens) -> the pooled (h/2 x w/2) level, quad-major again ([B][C/32][(h/4)*(w/4)][4][32];
+ * h % 4 == w % 4 == 0) or, with to_tokens, token-major [B][(h/2)*(w/2)][C] (the coarsest level's layout).  A pooled token's window
+ * is its quad's four children, summed in (row, col) order, then * 0.25: the values of casmtr_token_pool_fwd.  n <= 4.  (round 5) */
+int casmtr_quad_pool_fwd(const float* const* src, float* const* dst, int n, int B, int h, int w, int C, int to_tokens,
+                         casmtr_stream_t stream);
 
 /* F.avg_pool2d(kernel_size=2, stride=2) of the pyramid loop (quadtree_attention.py:82-90) on token-major tensors:
  * src_i [B,H,W,C] -> dst_i [B,H/2,W/2,C] for i < n <= 4 tensors in one launch (odd H/W: last row/column dropped,

@@ -146,3 +146,61 @@ def test_block_full_size_levels_bit_exact():
     assert np.array_equal(N(l0["topk_idx"]), levels[0]["topk_idx"])
     assert np.array_equal(N(l1["topk_idx"]), levels[1]["topk_idx"])
     assert_close(N(out), ref, 2e-5, "full-size block vs oracle")
+
+
+@pytest.mark.parametrize("B,h,w,Nn,K,nprob,bias", [(2, 12, 10, 64, 64, 3, True), (1, 26, 26, 256, 256, 2, False), (3, 8, 6, 32, 96, 1, True),
+                                                   (2, 52, 52, 128, 128, 4, True)])
+def test_linear_quads_equals_linear_then_layout(B, h, w, Nn, K, nprob, bias):
+    """casmtr_linear_quads_fwd (round 5): the projection GEMM writes the quad-major per-head layout itself -- bit for bit the values
+    of casmtr_linear_fwd re-laid by casmtr_tokens_to_quads (M not a multiple of the 128-row tile, several problems per launch)."""
+    from casmtr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + h)
+    xs = [torch.randn((B, h * w, K), generator=g).to(DEV) for _ in range(nprob)]
+    ws = [torch.randn((Nn, K), generator=g).to(DEV) for _ in range(nprob)]
+    bs = [torch.randn(Nn, generator=g).to(DEV) if bias and i != 1 else None for i in range(nprob)]
+    want = [ops.tokens_to_quads(y, h, w) for y in ops.linear_multi(xs, ws, bs)]
+    got = ops.linear_quads_multi(xs, ws, bs, h, w)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,h,w,C,n", [(2, 12, 8, 64, 3), (1, 52, 52, 256, 3), (3, 4, 4, 32, 1), (2, 10, 6, 96, 2)])
+def test_quad_pool_equals_token_pool(B, h, w, C, n):
+    """casmtr_quad_pool_fwd: the pyramid step on quad-major tensors = casmtr_token_pool_fwd on the token-major ones, written token-major
+    (the coarsest level) or quad-major again (h, w multiples of 4)."""
+    from casmtr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(h * 100 + w)
+    toks = [torch.randn((B, h * w, C), generator=g).to(DEV) for _ in range(n)]
+    quads = [ops.tokens_to_quads(t, h, w) for t in toks]
+    pooled = ops.token_pool_multi(toks, h, w)
+    for a, b in zip(ops.quad_pool_multi(quads, h, w, to_tokens=True), pooled):
+        assert torch.equal(a, b)
+    if h % 4 == 0 and w % 4 == 0:
+        for a, b in zip(ops.quad_pool_multi(quads, h, w), pooled):
+            assert torch.equal(a, ops.tokens_to_quads(b, h // 2, w // 2))
+    else:
+        with pytest.raises(RuntimeError):
+            ops.quad_pool_multi(quads, h, w)
+
+
+def test_block_routes_agree(monkeypatch):
+    """QuadtreeAttention / CascadeQuadtreeAttention on the quad-major route (projections written quad-major, pyramid on quad-major
+    levels, quad-major attention kernels: the default) against the round-2 token-major route (CASMTR_CALLER_LAYOUT=tokens): the two
+    kernel families select the same neighbours; the outputs agree to the softmax tolerance."""
+    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention
+    g = torch.Generator(device="cpu").manual_seed(9)
+    B, h, w, C, H = 2, 52, 52, 256, 8
+    x, tgt = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
+    m = QuadtreeAttention(C, H, [32, 16, 8], qkv_bias=True, scale=3).to(DEV).eval()
+    c = CascadeQuadtreeAttention(128, 4).to(DEV).eval()
+    hc = 26
+    xc, tc = torch.randn((B, 4 * hc * hc, 128), generator=g).to(DEV), torch.randn((B, 4 * hc * hc, 128), generator=g).to(DEV)
+    tp = torch.randint(2, hc - 2, (B, hc * hc, 1, 2), generator=g).to(DEV)
+    outs = {}
+    for route in ("tokens", "quads"):
+        monkeypatch.setenv("CASMTR_CALLER_LAYOUT", route)
+        with torch.no_grad():
+            outs[route] = (m(x, tgt, h, w), c(xc, tc, 2 * hc, 2 * hc, idx=tp, want_idx=False)[0])
+    for a, b, what in zip(outs["tokens"], outs["quads"], ("QuadtreeAttention", "CascadeQuadtreeAttention")):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(a.abs().max())), what
