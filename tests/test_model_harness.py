@@ -138,10 +138,22 @@ def test_coarse_stage_on_reference_features(fx):
     differ; the matcher then runs on the reference's own tokens and must reproduce its indices."""
     m = _model(fx, "cuda")
     f8 = torch.from_numpy(fx["f8"]).cuda().float()
-    data = _sizes(fx, {})
-    with torch.no_grad():
-        t0, t1 = m.coarse_stage(f8[:1], f8[1:], data)
-    _close(torch.cat([t0, t1]), fx["t8"].astype(np.float32), 3e-3, "1/8 tokens", frac=0.995)
+    # Two routes through the attention blocks (modules/quadtree_block.py).  "tokens": the token-major kernels (exact expf and division
+    # in the softmax): every element within 3e-3 of the reference's CPU result.  "quads" (the default since round 5: quad-major
+    # kernels, __expf / rcp softmax, values within 1e-6 of the other route per call -- tests/test_gpu_callers.py::test_block_routes_agree):
+    # in the second of the six layers 4 of the 1536 tokens sit on a top-k near-tie that those 1e-6 decide the other way, and four
+    # layers of global attention spread that: a few per cent of the elements move by up to 3e-2.  Per-operator parity (indices
+    # bit-exact on identical inputs) is what the other GPU tests pin; this one bounds the chained drift of the default route.
+    for route, bounds in (("tokens", ((3e-3, 0.995),)), ("quads", ((3e-3, 0.94), (1e-2, 0.995)))):
+        os.environ["CASMTR_CALLER_LAYOUT"] = route
+        try:
+            data = _sizes(fx, {})
+            with torch.no_grad():
+                t0, t1 = m.coarse_stage(f8[:1], f8[1:], data)
+        finally:
+            os.environ.pop("CASMTR_CALLER_LAYOUT", None)
+        for tol, frac in bounds:
+            _close(torch.cat([t0, t1]), fx["t8"].astype(np.float32), tol, f"1/8 tokens, {route} route", frac=frac)
     # the matcher on the reference's tokens
     t8 = torch.from_numpy(fx["t8"]).cuda().float()
     data = _sizes(fx, {})
