@@ -138,15 +138,23 @@ def _expected_exchanges(total, world, steps, warmup, every):
     return out
 
 
-def _run_mock_bench(every, total=5, world=2, steps=7, warmup=2):
+def _run_mock_bench(every, total=5, world=2, steps=7, warmup=2, launcher=True, extra=(), env=None):
+    """launcher=True: under `python -m torch.distributed.run` (the driver's documented N > 1 form); False: `python bench.py --gpus N`
+    as a plain process, which must re-execute itself under the launcher (bench.self_launch_cmd)"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup",
-           str(warmup), "--total-pairs", str(total), "--gather-every", str(every), "--mock-hotpath"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup",
+            str(warmup), "--total-pairs", str(total), "--gather-every", str(every), "--mock-hotpath", *extra]
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):   # a plain process is one that no launcher has prepared
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly ONE JSON line, from rank 0"
@@ -161,9 +169,40 @@ def test_bench_main_under_gloo_world2(every):
     """--gather-every 0 (one final exchange inside the timed region), 1 (per step) and 3 (windows of 3, last one partial)"""
     steps, warmup, total = 7, 2, 5
     d = _run_mock_bench(every, total=total, steps=steps, warmup=warmup)
-    assert d["mock"] and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["pairs_this_rank"] == 3 and d["first_timed_step"] == warmup
-    want = _expected_exchanges(total, 2, steps, warmup, every)
-    assert len(d["exchanges"]) == len(want) == {0: 1, 1: 7, 3: 3}[every]
+    check_mock_line(d, every, steps, warmup, total)
+
+
+def test_bench_self_launches_without_torchrun():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (how a driver that does not know about launchers starts an
+    N > 1 run) becomes two ranks under torch.distributed.run by itself and still prints exactly one JSON line"""
+    steps, warmup, total = 7, 2, 5
+    d = _run_mock_bench(3, total=total, steps=steps, warmup=warmup, launcher=False)
+    assert d["backend"] == "gloo"
+    check_mock_line(d, 3, steps, warmup, total)
+
+
+def test_self_launch_command_line():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_cmd", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.self_launch_cmd(8, ["--gpus", "8", "--steps", "20", "--warmup", "10"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-7] == os.path.join(root, "bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "10"]
+    port = int(bench.self_launch_cmd(2, [])[9])   # no port given: a free one is picked
+    assert 1024 < port < 65536
+
+
+def check_mock_line(d, every, steps, warmup, total, world=2):
+    """rank 0's line of a --mock-hotpath run against the lists recomputed here (shared with tests/test_gpu_dist_nccl.py)"""
+    from casmtr_amd import dist as cdist
+    lo, hi = cdist.shard_range(total, 0, world)
+    assert d["mock"] and d["n_gpus"] == world and d["scaling"] == "strong" and d["pairs_this_rank"] == hi - lo and d["first_timed_step"] == warmup
+    want = _expected_exchanges(total, world, steps, warmup, every)
+    assert len(d["exchanges"]) == len(want) == (1 if every == 0 else -(-steps // every))
     for got, w in zip(d["exchanges"], want):
         assert got["counts"] == w["counts"] and got["n_total"] == w["n_total"] and got["mk_shape"] == w["mk_shape"]
         assert got["sum_m_bids"] == w["sum_m_bids"], "global pair ids (shard offset + held-step offset)"

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,3 +24,34 @@ def test_bench_under_torchrun_with_rccl_group():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["matches_last_step"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: two ranks cannot share a device under RCCL")
+@pytest.mark.parametrize("every", [0, 1, 3])
+def test_two_rank_rccl(every):
+    """The first box with two GPUs runs the REAL two-rank RCCL exchange: `python bench.py --gpus 2 --mock-hotpath --mock-device cuda`
+    (self-launched, no torchrun on the command line) shards 5 pairs 3 + 2, broadcasts the parameter buffer, and gathers uneven, empty
+    and 20 000-entry device-resident lists to rank 0 (dist.gather to a non-dst rank, MatchGatherer.flush) at --gather-every 0 / 1 / 3;
+    the gathered lists must equal what a single process computes for all pairs (tests/test_dist_gloo.py::check_mock_line)."""
+    from test_dist_gloo import _run_mock_bench, check_mock_line
+    steps, warmup, total = 7, 2, 5
+    d = _run_mock_bench(every, total=total, steps=steps, warmup=warmup, launcher=False, extra=("--mock-device", "cuda"),
+                        env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["backend"] == "nccl" and d["device"].startswith("cuda")
+    check_mock_line(d, every, steps, warmup, total)
+
+
+def test_mock_device_cuda_single_rank_forced_rccl():
+    """what a 1-GPU box can check of the same code: the mock lists as DEVICE tensors through a forced one-rank RCCL group"""
+    env = dict(os.environ, CASMTR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+           "--total-pairs", "5", "--gather-every", "3", "--mock-hotpath", "--mock-device", "cuda"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["device"] == "cuda:0" and len(d["exchanges"]) == 2
+    from test_dist_gloo import _expected_exchanges
+    want = _expected_exchanges(5, 1, 4, 1, 3)
+    assert [g["counts"] for g in d["exchanges"]] == [w["counts"] for w in want]
+    assert [g["sum_m_bids"] for g in d["exchanges"]] == [w["sum_m_bids"] for w in want]
