@@ -257,6 +257,7 @@ int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mas
 // e = 2^-15 |a||b| / (C T) (the pair's largest norms: namax * nbmax) -> 4 e per factor, 8 e for the product, plus the two paths'
 // different summation orders (~1e-6).  `kthr` = 2^-14 / T (= 2 e per unit norm product).  Entries further apart than 2 * band
 // compare the same way in the exact path.
+#define DS_BAND_MAX 0.04f   // 2 band must stay below the 0.1 margin of cmin = 0.9 thr (ds_xnear_kernel raises the exact fallback beyond it)
 __device__ __forceinline__ float ds_conf_band(float kthr, unsigned namax_bits, unsigned nbmax_bits) {
     return 4.25f * kthr * __uint_as_float(namax_bits) * __uint_as_float(nbmax_bits) + 4e-6f;
 }

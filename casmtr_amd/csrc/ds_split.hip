@@ -894,11 +894,15 @@ __device__ __forceinline__ void wave_lds_fence_() {   // this wave's LDS writes 
 __global__ __launch_bounds__(256) void ds_xnear_kernel(DsWs w, int L, int total, float thr, float kthr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
+    const int b = t / L;
+    const float band = ds_conf_band(kthr, w.namax[b], w.nbmax[b]);
+    // The borderline lists only take entries above cmin = 0.9 thr (pass 2), i.e. they assume 2 band < 0.1.  Large-norm features
+    // (|a||b| / (C T) in the hundreds: band grows with namax nbmax) break that assumption: a runner-up below 0.9 thr could exactly
+    // exceed thr or its line's best and would never be listed.  Such a pair hands every decision to the exact passes instead.
+    if (band > DS_BAND_MAX) { *w.ovf = 1; return; }
     const unsigned long long key = w.rbest[t];
     if (!key) return;
     const float cf = __uint_as_float((unsigned)(key >> 32));
-    const int b = t / L;
-    const float band = ds_conf_band(kthr, w.namax[b], w.nbmax[b]);
     if (fabsf(cf - thr) <= band * fmaxf(cf, thr)) ds_x_append(w, t, (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)));
 }
 
@@ -1267,12 +1271,15 @@ int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mas
     hipLaunchKernelGGL(ds_xdecide_kernel, dim3(256), dim3(256), 0, s, w, L, S, thr);
     CASMTR_CHECK_LAUNCH();
     if (getenv("CASMTR_DS_DEBUG")) {   // diagnostic only: synchronises
-        int cnt[4] = {0, 0, 0, 0}, ln[128] = {0};
+        int cnt[4] = {0, 0, 0, 0};
+        int* ln = (int*)calloc((size_t)2 * B, sizeof(int));   // xln: [B] listed rows, then [B] listed columns
+        if (!ln) return 0;
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(cnt, w.xcnt, sizeof cnt, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(ln, w.xln, sizeof(int) * (size_t)(2 * B < 128 ? 2 * B : 128), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ln, w.xln, sizeof(int) * (size_t)(2 * B), hipMemcpyDeviceToHost);
         int nr = 0, ncol = 0;
-        for (int i = 0; i < B && i < 64; ++i) { nr += ln[i]; ncol += ln[B + i]; }
+        for (int i = 0; i < B; ++i) { nr += ln[i]; ncol += ln[B + i]; }
+        free(ln);
         fprintf(stderr, "ds_xdecide: %d borderline entries, %d rows + %d columns recomputed exactly (B = %d, L = %d, S = %d)\n", cnt[0], nr,
                 ncol, B, L, S);
     }

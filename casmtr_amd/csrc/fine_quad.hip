@@ -567,14 +567,6 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     flush();
 }
 
-// fine_vs.hip, fine_lw.hip
-int casmtr_qta_fine_level_vs(const float* q, const float* key, const float* value, const int32_t* parents, float temp, float w_level,
-                             const float* acc_in, float* message, float* acc_out, int B, int h0, int w0, int h1, int w1, int H, int Kp,
-                             hipStream_t s);
-int casmtr_qta_fine_level_lw(const float* q, const float* key, const float* value, const int32_t* parents, float temp, float w_level,
-                             const float* acc_in, float* message, float* acc_out, int B, int h0, int w0, int h1, int w1, int H, int Kp,
-                             hipStream_t s);
-
 template <int NPASS, bool EXACT, bool FULL>
 static int launch_fine_quad(const FineQArgs& a, hipStream_t s) {
     constexpr size_t lds = 2 * sizeof(float) * (2048 + 8 * (32 * NPASS + 4) + 2 * 256);
@@ -648,17 +640,6 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
     { const char* ev = getenv("CASMTR_FQ_FLAGS"); a.xflags = ev ? atoi(ev) : 0; }
     hipStream_t s = (hipStream_t)stream;
     const bool full = K == 64 || K == 128;
-    if (topk == 0 && K == 64) {   // the finest level of every shipped config
-        const char* ev = getenv("CASMTR_FQ_VARIANT");   // experiments of round 5, bit-equal results: "lw", "vs"
-        if (ev && ev[0] == 'l') {
-            const int r = casmtr_qta_fine_level_lw(q, key, value, parents, temp, w_level, acc_in, message, acc_out, B, h0, w0, h1, w1, H, Kp, s);
-            if (r != CASMTR_ERR_UNSUPPORTED) return r;
-        }
-        if (ev && ev[0] == 'v') {
-            const int r = casmtr_qta_fine_level_vs(q, key, value, parents, temp, w_level, acc_in, message, acc_out, B, h0, w0, h1, w1, H, Kp, s);
-            if (r != CASMTR_ERR_UNSUPPORTED) return r;
-        }
-    }
     if (topk > 0) {
         if (K <= 64) return full ? launch_fine_quad<1, true, true>(a, s) : launch_fine_quad<1, true, false>(a, s);
         return full ? launch_fine_quad<2, true, true>(a, s) : launch_fine_quad<2, true, false>(a, s);

@@ -134,6 +134,10 @@ class QTAttB(nn.Module):
         return final.contiguous()
 
     # ---- fused path -------------------------------------------------------------------------------------------
+    # test / audit hook: forward_tokens and forward_quads also materialise the per-level top-k tensors the reference keeps internal
+    # (:219-227) and leave the per-level results in self._last_levels (tests/test_model_harness.py audits chained near-tie flips)
+    keep_levels = False
+
     def _level_weights(self):
         """softmax(self.weight) as python floats (they are kernel arguments).  Reading them back is a host sync, so the
         result is cached until the parameter is modified (tensor version counter / storage change)."""
@@ -237,9 +241,10 @@ class QTAttB(nn.Module):
             raise RuntimeError("QTAttB.forward_quads is the inference path (no lepe, no autograd): use forward()")
         hq, hk = list(reversed(hw_q)), list(reversed(hw_k))
         weight = self._level_weights()
-        out = ops.qta_coarse_level(*coarsest, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=False)
+        keep = self.keep_levels
+        out = ops.qta_coarse_level(*coarsest, self.nhead, self.topks[0], w_level=weight[0], want_message=False, want_tab=True, want_topk=keep)
         quads = [t for lvl in reversed(finer) for t in lvl]
-        return self._finer_levels_quad(out, quads, hq, hk, weight)
+        return self._finer_levels_quad(out, quads, hq, hk, weight, want_topk=keep)
 
     def forward_multi(self, calls, split_fine=False):
         """calls: list of (queries, keys, values) pyramid triples of identical shapes whose results do not depend on each other -- the two
@@ -320,6 +325,7 @@ class QTAttB(nn.Module):
         n = len(levels)
         weight = self._level_weights()
         acc = prev_idx = None
+        per_level = []
         for i, (q, k, v) in enumerate(levels):
             if i == 0:
                 out = ops.qta_coarse_level(q, k, v, self.nhead, self.topks[0], w_level=weight[0], want_message=False)
@@ -329,6 +335,8 @@ class QTAttB(nn.Module):
                 out = ops.qta_fine_level(q, k, v, prev_idx, hw_q[i], hw_k[i], self.nhead, topk, w_level=weight[i],
                                          acc_in=acc, want_message=False)
             acc, prev_idx = out["acc"], out["topk_idx"]
+            per_level.append(out)
+        self._last_levels = per_level if self.keep_levels else None
         return acc
 
     def forward_tokens(self, queries, keys, values, hw_q, hw_k):

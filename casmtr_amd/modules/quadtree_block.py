@@ -8,6 +8,8 @@ The reference takes [B,N,C] tokens, permutes them to NCHW (+ contiguous), applie
 avg-pool pyramid in NCHW, and QTAttB turns every level back into tokens.  The inference path here never leaves the token
 layout: one batched fp32-MFMA GEMM launch for the three projections, one pooling launch per pyramid level for q/k/v
 together, the fused level kernels on those buffers, one GEMM for the output projection.  No layout kernel runs at all.
+Two routes do that (see _quad_route): token-major throughout (the default: exact expf / division softmax, what the chained
+reference-parity tests pin), or quad-major operands written by the projections themselves (opt-in: the hot path's kernels).
 
 With autograd (training), `attn_type` 'A' / 'Guided', `lepe` or a QTAttB `rel_pos`, forward() keeps the reference's
 structure on torch ops + the composed attention modules.
@@ -63,9 +65,27 @@ def _project_qkv_quads(mod, x, target, hw, hw1):
     return q, k, v
 
 
-def _quad_route():
+def _quad_route(mod):
+    """Which kernels serve a block's inference forward.  "tokens" (default): token-major projections and the token-major attention
+    kernels, whose softmax uses expf and a true division -- the route the chained reference-parity tests hold to 3e-3
+    (tests/test_model_harness.py).  "quads": the projections write the quad-major operand layout and the quad-major kernels of the
+    hot path run (hardware exponential + reciprocal: per call the same indices, values within 2e-5 of the other route; over a chain
+    of layers those 1e-6 can decide a top-k near-tie the other way).  The throughput-oriented callers opt in explicitly:
+    pipeline.HotPath (cfg.caller_layout), model.timing, set_caller_layout(); CASMTR_CALLER_LAYOUT sets the default for blocks that
+    were not told."""
     import os
-    return os.environ.get("CASMTR_CALLER_LAYOUT", "quads") == "quads"   # "tokens": the round-2 token-major route (tests compare the two)
+    return (mod.layout or os.environ.get("CASMTR_CALLER_LAYOUT", "tokens")) == "quads"
+
+
+def set_caller_layout(module, layout):
+    """layout 'tokens' | 'quads' | None (= the CASMTR_CALLER_LAYOUT default) for every QuadtreeAttention / CascadeQuadtreeAttention
+    inside `module`; returns the module"""
+    if layout not in ("tokens", "quads", None):
+        raise ValueError(f"caller layout {layout!r} (tokens | quads | None)")
+    for m in module.modules():
+        if isinstance(m, (QuadtreeAttention, CascadeQuadtreeAttention)):
+            m.layout = layout
+    return module
 
 
 class QuadtreeAttention(nn.Module):
@@ -89,6 +109,7 @@ class QuadtreeAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.scale = scale
+        self.layout = None   # see _quad_route
         self.apply(_init_weights)
 
     def _fused_ok(self, x, target, rel_pos):
@@ -104,7 +125,7 @@ class QuadtreeAttention(nn.Module):
             return self._forward_reference_structure(x, target, H, W, H1, W1, rel_pos, topk_pos)
         hw_q = [(H >> i, W >> i) for i in range(self.scale)]
         hw_k = [(H1 >> i, W1 >> i) for i in range(self.scale)]
-        if (_quad_route() and self.scale > 1 and C % 32 == 0 and all(h % 2 == 0 and w % 2 == 0 for h, w in hw_q[:-1] + hw_k[:-1])
+        if (_quad_route(self) and self.scale > 1 and C % 32 == 0 and all(h % 2 == 0 and w % 2 == 0 for h, w in hw_q[:-1] + hw_k[:-1])
                 and self.py_att.quads_ok(hw_q, hw_k)):
             # projections straight into the fine-level kernels' quad-major layout, pyramid on quad-major levels, the coarsest level
             # pooled into the token-major layout its kernel reads: no layout pass anywhere (round 5)
@@ -171,6 +192,7 @@ class CascadeQuadtreeAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.scale = scale
+        self.layout = None   # see _quad_route
         self.apply(_init_weights)
 
     def forward(self, x, target, H, W, H1=None, W1=None, idx=None, rel_pos=None, want_idx=True):
@@ -182,7 +204,7 @@ class CascadeQuadtreeAttention(nn.Module):
         if rel_pos is not None:
             rel_pos = rel_pos.to(torch.float32)
         if x.is_cuda and not _needs_autograd(x, target, rel_pos, *self.parameters()):
-            if (not want_idx and _quad_route() and C % 32 == 0 and H % 2 == 0 and W % 2 == 0 and H1 % 2 == 0 and W1 % 2 == 0
+            if (not want_idx and _quad_route(self) and C % 32 == 0 and H % 2 == 0 and W % 2 == 0 and H1 % 2 == 0 and W1 % 2 == 0
                     and self.cross_attn.quads_ok((H, W), (H1, W1), idx.shape[2])):
                 q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
                 msg = self.cross_attn.forward_quads(q, k, v, (H, W), (H1, W1), idx, rel_pos)

@@ -186,6 +186,11 @@ def linear(x, w, bias=None):
     return linear_multi([x], [w], [bias])[0]
 
 
+def linear_gemm_mode():
+    """how casmtr_linear[_quads]_fwd multiplies: 'exact' = the fp32 MFMA fmaf chain (v_mfma_f32_32x32x2_f32, k ascending)"""
+    return "exact"
+
+
 def linear_quads_multi(xs, ws, biases, h, w):
     """linear_multi with the results written quad-major per head: x_i [B, h*w, K] -> [B, N/32, (h/2)*(w/2), 4, 32] (the layout
     tokens_to_quads produces), one launch, no layout pass.  h, w even, N % 32 == 0."""
@@ -317,7 +322,7 @@ def qta_coarse_level(q, k, v, nhead, topk, w_level=None, want_message=True, want
             rc = l.casmtr_qta_coarse_level_tab_fwd(_ptr(q), _ptr(k), _ptr(v), 1.0 / D ** 0.5, topk,
                                                    0.0 if w_level is None else float(w_level), _ptr(ws), _ptr(msg),
                                                    _ptr(acc), _ptr(ts), _ptr(ti), _ptr(tab), B, L, S, nhead, D, _stream())
-        if rc == _lib.ERR_UNSUPPORTED and not want_topk:   # a kernel variant that cannot skip the lists (CASMTR_COARSE_KERNEL=fused)
+        if rc == _lib.ERR_UNSUPPORTED and not want_topk:   # a kernel that cannot skip the int64 lists declined: ask again with them
             want_topk = True
             continue
         _lib.check(rc, "qta_coarse_level_fwd")

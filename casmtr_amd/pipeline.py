@@ -23,7 +23,7 @@ from . import ops
 from .matching.cascade_matching import CascadeMatching
 from .matching.coarse_matching import CoarseMatching
 from .modules.quadtree_attention import CascadeQTAttB, QTAttB
-from .modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention
+from .modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention, set_caller_layout
 
 
 @dataclass
@@ -59,6 +59,8 @@ class HotPathConfig:
     materialize_conf: bool = False    # data['stage_8c']['conf_matrix'] is not consumed at inference
     callers: bool = False             # enter through QuadtreeAttention / CascadeQuadtreeAttention
                                       # ([B,N,C] tokens in; q/k/v + output projections and the pyramid inside the step)
+    caller_layout: str = "quads"      # callers only: the blocks' route (modules/quadtree_block.py::_quad_route); the throughput path opts into
+                                      # the quad-major kernels, the nn.Module default stays token-major
     masked: bool = False              # MegaDepth-style padding masks (BASELINE configs[2]): bottom / right up to 20 % padded
     fresh_inputs: bool = True         # every attention layer reads its own q/k/v tensors (False: one shared set, as round 1)
     paired_layers: object = "coarse"  # False | True | "coarse".  The two directions of a layer are independent in the reference
@@ -210,6 +212,7 @@ class HotPath(torch.nn.Module):
             self.cascade_blocks = torch.nn.ModuleList(
                 torch.nn.ModuleList(unit_gain(CascadeQuadtreeAttention(st.dim, st.heads)) for _ in range(st.cross_layers))
                 for st in cfg.stages)
+            set_caller_layout(self, cfg.caller_layout)
         self.coarse_matching = CoarseMatching(
             {"thr": cfg.coarse_thr, "border_rm": cfg.coarse_border_rm, "train_coarse_percent": 0.3,
              "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.coarse_temperature},

@@ -70,9 +70,10 @@ int casmtr_nchw_to_tokens_multi(const float* const* src, float* const* dst, cons
 
 /* QTAttB.process_coarse_level (modules/quadtree_attention.py:161-178): dense QK^T (fp32 MFMA) -> softmax over S
  * -> top-k -> A.V.   q [B,L,H,D], k/v [B,S,H,D].
- *   logits_ws : workspace of casmtr_qta_coarse_level_ws_floats(B,L,S,H) floats ([B,H,L,S_pad] logits, S_pad = round_up(S,64),
- *               + [B,H,L,2] row maxima / sums) for the three-kernel path (default); the fused single-kernel path (CASMTR_COARSE_KERNEL=fused, S <= 1024) keeps the tile
- *               in LDS and needs none (ws_floats then returns 1)
+ *   logits_ws : workspace of casmtr_qta_coarse_level_ws_floats_k(B,L,S,H,topk) floats: 1 (unused) when the register-tile kernel
+ *               serves the shape (coarse_tile_kernel: S <= 1024, topk <= 60 -- the default for every shipped config); otherwise, and
+ *               with CASMTR_COARSE_KERNEL=three, the three-kernel path's [B,H,L,S_pad] logits (S_pad = round_up(S,64)) + [B,H,L,2]
+ *               row maxima / sums
  *   message [B,L,H,D]; acc_out [B,L,H,D] = message * w_level (NULL to skip); topk_score/topk_idx [B,L,topk,H]  */
 int casmtr_qta_coarse_level_fwd(const float* q, const float* k, const float* v, float temp, int topk, float w_level,
                                 float* logits_ws, float* message, float* acc_out, float* topk_score,

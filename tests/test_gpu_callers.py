@@ -185,22 +185,46 @@ def test_quad_pool_equals_token_pool(B, h, w, C, n):
 
 def test_block_routes_agree(monkeypatch):
     """QuadtreeAttention / CascadeQuadtreeAttention on the quad-major route (projections written quad-major, pyramid on quad-major
-    levels, quad-major attention kernels: the default) against the round-2 token-major route (CASMTR_CALLER_LAYOUT=tokens): the two
-    kernel families select the same neighbours; the outputs agree to the softmax tolerance."""
-    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention
+    levels, quad-major attention kernels: opt-in, `layout = "quads"`) against the token-major route (the modules' default): the two
+    kernel families select the same neighbours; the outputs agree to the softmax tolerance.  The test also checks that the route it
+    names is the route that ran (with KW = 1 windows both 'routes' of the cascade block ran the token-major kernel)."""
+    from casmtr_amd import ops
+    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention, set_caller_layout
     g = torch.Generator(device="cpu").manual_seed(9)
     B, h, w, C, H = 2, 52, 52, 256, 8
     x, tgt = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
     m = QuadtreeAttention(C, H, [32, 16, 8], qkv_bias=True, scale=3).to(DEV).eval()
-    c = CascadeQuadtreeAttention(128, 4).to(DEV).eval()
-    hc = 26
-    xc, tc = torch.randn((B, 4 * hc * hc, 128), generator=g).to(DEV), torch.randn((B, 4 * hc * hc, 128), generator=g).to(DEV)
-    tp = torch.randint(2, hc - 2, (B, hc * hc, 1, 2), generator=g).to(DEV)
+    c = CascadeQuadtreeAttention(128, 4, qkv_bias=True).to(DEV).eval()
+    assert m.layout is None and c.layout is None, "blocks are born on the default (token-major) route"
+    calls = {}
+    for name in ("cascade_attn_quad", "cascade_attn", "linear_quads_multi", "qta_fine_level_quad", "qta_fine_level"):
+        def spy(*a, _f=getattr(ops, name), _n=name, **k):
+            calls[_n] = calls.get(_n, 0) + 1
+            return _f(*a, **k)
+        monkeypatch.setattr(ops, name, spy)
+    # 5 x 5 windows around random coarse matches (transformer.py:416-440), same grids and different grids (H,W != H1,W1), with and
+    # without the relative position bias of the indoor config ([B, nhead, H0*W0, 4*25])
+    cases = []
+    for (hq, wq), (hk, wk), rel in (((26, 26), (26, 26), False), ((26, 26), (26, 26), True), ((20, 26), (30, 22), False), ((20, 26), (30, 22), True)):
+        xc = torch.randn((B, 4 * hq * wq, 128), generator=g).to(DEV)
+        tc = torch.randn((B, 4 * hk * wk, 128), generator=g).to(DEV)
+        tp = ops.window_warp_idx(torch.randint(0, hk * wk, (B, hq * wq), generator=g).to(DEV), hk, wk, 5)
+        assert tuple(tp.shape) == (B, hq * wq, 25, 2)
+        rp = torch.randn((B, 4, 4 * hq * wq, 100), generator=g).to(DEV) if rel else None
+        cases.append((xc, tc, (2 * hq, 2 * wq), (2 * hk, 2 * wk), tp, rp))
     outs = {}
     for route in ("tokens", "quads"):
-        monkeypatch.setenv("CASMTR_CALLER_LAYOUT", route)
+        set_caller_layout(m, route), set_caller_layout(c, route)
+        calls.clear()
         with torch.no_grad():
-            outs[route] = (m(x, tgt, h, w), c(xc, tc, 2 * hc, 2 * hc, idx=tp, want_idx=False)[0])
-    for a, b, what in zip(outs["tokens"], outs["quads"], ("QuadtreeAttention", "CascadeQuadtreeAttention")):
+            outs[route] = [m(x, tgt, h, w)] + [c(xc, tc, *hwq, *hwk, idx=tp, rel_pos=rp, want_idx=False)[0] for xc, tc, hwq, hwk, tp, rp in cases]
+        if route == "quads":
+            assert calls.get("cascade_attn_quad") == len(cases) and not calls.get("cascade_attn"), calls
+            assert calls.get("linear_quads_multi", 0) >= 1 + len(cases) and calls.get("qta_fine_level_quad") == 2 and not calls.get("qta_fine_level"), calls
+        else:
+            assert calls.get("cascade_attn") == len(cases) and not calls.get("cascade_attn_quad") and not calls.get("linear_quads_multi"), calls
+            assert calls.get("qta_fine_level") == 2 and not calls.get("qta_fine_level_quad"), calls
+    names = ["QuadtreeAttention"] + [f"CascadeQuadtreeAttention {hwq}->{hwk}{' rel_pos' if rp is not None else ''}" for _, _, hwq, hwk, _, rp in cases]
+    for a, b, what in zip(outs["tokens"], outs["quads"], names):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(a.abs().max())), what

@@ -267,3 +267,26 @@ def test_split_borderline_overflow_falls_back_to_exact(ops):
         ex = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=False, gemm="exact")
         sp = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=False, gemm="split")
         _assert_same_lists(sp, ex, f"duplicated rows, thr = {thr}")
+
+
+@pytest.mark.parametrize("want_conf", [False, True])
+def test_split_large_norm_features_fall_back_to_exact(ops, want_conf):
+    """ADVICE r05 (ds_conf_band has no cap).  Unnormalised, large-norm features: |a||b| / (C T) in the hundreds makes the confidence
+    band of the split path wider than the 0.1 margin the borderline lists assume (they drop entries below 0.9 thr), so a runner-up
+    that the exact path accepts could go unlisted.  Such a pair must take the exact passes (ds_xnear_kernel raises the fallback
+    flag when band > DS_BAND_MAX): lists, indices and confidences are then the exact path's."""
+    g = torch.Generator(device="cpu").manual_seed(33)
+    B, h, w, C = 2, 20, 24, 256
+    L = h * w
+    f0 = 6.0 * torch.randn((B, L, C), generator=g)            # |a| / sqrt(C) ~ 6: namax * nbmax ~ 40 > 19 (band > 0.04 at T = 0.1)
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(B)])
+    f1 = torch.stack([f0[b][perm[b]] for b in range(B)]) + 1.5 * torch.randn((B, L, C), generator=g)
+    f0[1] *= 0.1                                               # the second pair stays inside the band's assumptions (per-pair bound)
+    f1[1] *= 0.1
+    f0, f1 = f0.to(DEV).contiguous(), f1.to(DEV).contiguous()
+    for thr in (0.2, 0.02):
+        ex = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=want_conf, gemm="exact")
+        sp = ops.dual_softmax(f0, f1, (h, w), (h, w), 0.1, thr, want_conf=want_conf, gemm="split")
+        _assert_same_lists(sp, ex, f"large-norm features, thr = {thr}")
+        assert torch.equal(sp["next_idx_c01"], ex["next_idx_c01"]) and torch.equal(sp["next_idx_c10"], ex["next_idx_c10"])
+        assert torch.equal(sp["next_conf_c01"], ex["next_conf_c01"]), "the exact passes ran: confidences are the exact path's bit for bit"
