@@ -42,6 +42,10 @@ struct CasQArgs {
     int hw;                // heads a wave walks per sub-item (divides H): the XCDs split into H / hw head groups x 8 hw / H item chunks
     int colmajor;          // item order inside an XCD's chunk: 1 = down the columns of quad pairs (consecutive items of a wave's neighbours
                            // share 4 of their 5 window rows), 0 = along the rows
+    int* ctr;              // nullable: work_counters() -- items beyond a wave's first two are CLAIMED (atomic counter per XCD) instead of dealt
+                           // out with a fixed stride: the waves of an XCD then always work on one compact front of ~2 x (waves per XCD)
+                           // consecutive items (the window boxes of a front share the L2), and a wave that drew expensive items (incoherent
+                           // windows: 25.6 KB straight from HBM) simply takes fewer
 };
 
 struct Sub {   // one sub-item: the candidate rows of `ncells` cells against nq query quads (all wave-uniform)
@@ -70,7 +74,24 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     const int chunk = (a.nitems + G - 1) / G, cnt = min(chunk, a.nitems - g * chunk);
     const int total = cnt > 0 ? a.B * cnt : 0, stride = (gridDim.x >> 3) * 2;
     int t = (blockIdx.x >> 3) * 2 + wave;
-    if (g >= G || t >= total) return;
+    int* const ctr = a.ctr ? a.ctr + xcd : nullptr;
+    // dynamic claiming: every wave of this XCD's share of the grid reports in once when it leaves; the last one re-zeroes the pair
+    auto leave = [&]() {
+        if (ctr && lane == 0 && atomicAdd(ctr + 8, 1) == stride - 1) { atomicExch(ctr, 0); atomicExch(ctr + 8, 0); }
+    };
+    if (g >= G || t >= total) { leave(); return; }
+    int t_claim = 0;       // lane 0: the item claimed behind the last prefetch (an atomic with return: valid once it has come back)
+    bool t_have = true;    // `t` holds the next item to prefetch (false: it is still in t_claim)
+    auto claim = [&]() {   // right behind a prefetch: the item after that one
+        if (ctr) {
+            if (lane == 0) t_claim = atomicAdd(ctr, 1) + 2 * stride;   // items 0 .. 2 stride - 1 are the waves' static first two
+            t_have = false;
+        } else t += stride;
+    };
+    auto next_t = [&]() {
+        if (!t_have) { t = __builtin_amdgcn_readfirstlane(t_claim); t_have = true; }
+        return t;
+    };
     for (int i = lane; i < 2048; i += 64) ring[i] = 0.f;    // rows of a short last chunk that no DMA ever wrote must be finite
     lds_reads_done();
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     t += stride;
     stage_in();
     sub_cur = sub_nx;
-    if (!regs_full && t < total) { prefetch(t); t += stride; }
+    if (!regs_full && t < total) { prefetch(t); claim(); }
     int hcur = h0, ubuf = 0;   // head of the current unit, its query staging buffer
     issue_q(sub_cur.b, sub_cur.quadA, sub_cur.hasB, h0, 0);
     // results of the previous unit: stored right behind the next one's first DMA wait
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             else if constexpr (c == 3) { if (more) glds_wait<4>(); else glds_wait<0>(); }
             else glds_wait<4>();
             if constexpr (c == 2) {
-                if (!same && more_sub && !regs_full && t < total) { prefetch(t); t += stride; }   // issued behind the wait
+                if (!same && more_sub && !regs_full && next_t() < total) { prefetch(t); claim(); }   // issued behind the wait
             }
             const int nmm = c < 3 ? 16 : (nrow3 >> 1);   // valid row pairs of this chunk
             float vb[16];
@@ -410,6 +431,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     }
     glds_wait<0>();
     flush();
+    leave();
 }
 
 template <bool HAS_REL>
@@ -451,6 +473,7 @@ extern "C" int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, co
     // 22.0 / 22.0 ms: there the kernel is bound by its memory traffic, not by its instruction stream.  Default: one head per wave
     // (XCD <-> head, the round-3 mapping).
     a.hw = 1;
+    { const char* ev = getenv("CASMTR_CQ_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters(); }
     { const char* ev = getenv("CASMTR_CQ_HEADS_PER_WAVE"); const int v = ev ? atoi(ev) : 0; if (v >= 1 && v <= nhead && nhead % v == 0 && (8 % (nhead / v)) == 0) a.hw = v; }
     return rel_pos ? launch_cas_quad<true>(a, (hipStream_t)stream) : launch_cas_quad<false>(a, (hipStream_t)stream);
 }

@@ -200,7 +200,11 @@ __device__ __forceinline__ float sum_over_slices8(float x) {
     return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
-// prof.hip
+// prof.hip.  Work counters of the persistent gather kernels (dynamic item claiming): -> 16 zeroed ints on the current device, [0..7] the
+// per-XCD claim counters, [8..15] the per-XCD exit counters.  The kernels leave them zero again (the last wave of an XCD to exit resets
+// its pair), so a slot needs no clearing launch; slots rotate (64 per device) so that launches in flight on different streams do not
+// share one.  nullptr on allocation failure (callers then use their static schedule).
+int* work_counters();
 extern int g_debug_flags;   // casmtr_debug_set(): phase-elimination switches for timing experiments (results become garbage)
 #define CASMTR_DBG_NO_DMA 1      // DMA kernels: do not issue / wait for the key and value row transfers
 #define CASMTR_DBG_NO_MATH 2     // DMA kernels: skip the per-stage LDS reads and arithmetic

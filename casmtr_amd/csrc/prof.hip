@@ -10,6 +10,22 @@
 #include "../../include/casmtr_hip.h"
 
 namespace casmtr {
+int* work_counters() {
+    constexpr int NSLOT = 64;
+    static int* base[CASMTR_MAX_DEVICES] = {nullptr};
+    static unsigned seq[CASMTR_MAX_DEVICES] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return nullptr;
+    int* p = __atomic_load_n(&base[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        if (hipMalloc(&p, sizeof(int) * 16 * NSLOT) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, sizeof(int) * 16 * NSLOT) != hipSuccess) { (void)hipFree(p); return nullptr; }   // synchronous, once per device
+        int* expect = nullptr;
+        if (!__atomic_compare_exchange_n(&base[dev], &expect, p, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { (void)hipFree(p); p = expect; }
+    }
+    return p + 16 * (__atomic_fetch_add(&seq[dev], 1u, __ATOMIC_RELAXED) % NSLOT);
+}
+
 int g_debug_flags = 0;
 static unsigned g_mask = 0;   // bit id set: kernel id is being timed
 struct Pair { hipEvent_t a, b; };
