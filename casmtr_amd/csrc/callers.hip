@@ -180,6 +180,262 @@ extern "C" int casmtr_linear_quads_fwd(const float* const* x, const float* const
     return linear_launch(x, w, bias, y, nprob, M, N, K, h, w_, stream);
 }
 
+// =================================================================================================== projections on the f16 matrix pipe
+// The same projections, fp32-accurate, on v_mfma_f32_32x32x16_f16: the two-term f16 split of ds_split.hip applied to
+// y = x . w^T.  fp32 MFMA runs at the fp32 vector rate (1/16 of the f16 MFMA rate) and linear_nt_kernel sits at 63 % of it; the
+// reference's own conv / linear is a BLAS call with unspecified accumulation order (TF32 under torch 1.10), so the contract of this path
+// is a tolerance, not the chain: every operand row is scaled by a power of two so that its largest element lies in [512, 1024) and
+// split a = hi + lo + r, hi = f16(a), lo = f16(a - hi), |r| <= 2^-22 |a|; f16 x f16 is exact in fp32, so
+//      x.w  ~  lo_x.hi_w + hi_x.lo_w + hi_x.hi_w        (dropped: lo.lo and the r terms, <= 3 x 2^-22 sum|x w|),
+// accumulated in fp32 over K / 16 MFMA steps: |y_split - y_chain| <= 2^-15 |x_m| |w_n| (the budget of ds_split.hip, K <= 256; measured
+// ~1e-7 |x||w|, tests/test_gpu_callers.py).  Default stays the exact chain (casmtr_linear_fwd); callers opt in (ops.linear_multi(gemm=)).
+//   * weights: split once into the GEMM's tile image (casmtr_linear_split_prep; cached by the caller per weight tensor):
+//       img[jb = n / 128][ks = k / 32][kg = (k / 8) % 4][part hi | lo][row n % 128][8 f16]  (16 KB per (jb, ks)), fac[n] = 2^e_n
+//   * activations: one wave per row finds the exponent (lin_rowexp_kernel: M ints); the GEMM reads the fp32 rows itself and splits them on
+//     the way into LDS (no activation image in HBM: the kernel is bound by reading x and writing y, 64 flop per byte at K = N = 256)
+//   * linear16_kernel: linear_nt_kernel's structure (128 x 128 tile, 4 waves x 64 x 64, next k-chunk prefetched into registers under the
+//     MFMAs of the current one), 12 MFMAs per wave and 16 channels, small terms first; epilogue acc * 2^e_m * 2^e_n + bias, token-major or
+//     quad-major rows exactly as linear_nt_kernel.
+typedef _Float16 l16_h8 __attribute__((ext_vector_type(8)));
+
+struct Linear16Batch {
+    const float* x[LIN_MAXP];
+    const int* ex[LIN_MAXP];        // [M] row exponents of x_p
+    const char* wimg[LIN_MAXP];     // weight tile image
+    const float* wfac[LIN_MAXP];    // [N] 2^e_n
+    const float* bias[LIN_MAXP];    // nullable
+    float* y[LIN_MAXP];
+    int qh, qw;
+    unsigned magic_w;
+};
+
+// wave per row: e = exponent that puts the row's largest |element| into [512, 1024) (ds_rownorm_kernel's rule)
+__global__ __launch_bounds__(256) void lin_rowexp_kernel(const float* __restrict__ x, int M, int K, int* __restrict__ ex) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* p = x + (size_t)row * K;
+    float mx = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = wave_max_f32(mx);
+    if (lane == 0) ex[row] = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
+}
+
+// workgroup per weight row: exponent, factor, split into the tile image (N x K <= 64 K elements: latency-bound, run once per weight)
+__global__ __launch_bounds__(64) void lin_wprep_kernel(const float* __restrict__ w, int N, int K, char* __restrict__ img, float* __restrict__ fac) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float* p = w + (size_t)n * K;
+    float mx = 0.f;
+    for (int c = lane; c < K; c += 64) mx = fmaxf(mx, fabsf(p[c]));
+    mx = wave_max_f32(mx);
+    const int e = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
+    if (lane == 0) fac[n] = ldexpf(1.0f, e);
+    for (int g8 = lane; g8 < K / 8; g8 += 64) {
+        l16_h8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xn = ldexpf(p[8 * g8 + c], -e);
+            const _Float16 h = (_Float16)xn;
+            hi[c] = h;
+            lo[c] = (_Float16)(xn - (float)h);
+        }
+        char* o = img + ((size_t)(n >> 7) * (K / 32) + (g8 >> 2)) * 16384 + (g8 & 3) * 4096 + (n & 127) * 16;
+        *reinterpret_cast<l16_h8*>(o) = hi;
+        *reinterpret_cast<l16_h8*>(o + 2048) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void linear16_kernel(const Linear16Batch lb, int M, int N, int K, int NJB) {
+    __shared__ __attribute__((aligned(16))) char As[16384];   // one k-chunk of 32 channels: [kg 4][hi | lo][128 rows][8 f16]
+    __shared__ __attribute__((aligned(16))) char Bs[16384];
+    __shared__ float facA[LIN_BM], facB[LIN_BN];
+    const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
+    const int tI = t / NJB, tJ = t - tI * NJB;
+    const int p = blockIdx.y, i0 = tI * LIN_BM, j0 = tJ * LIN_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int KS = K >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // activations: thread <-> (row tid / 2, 16 channels of the chunk): two kg planes of the image
+    const int lrow = tid >> 1, half = tid & 1;
+    const int gi = i0 + lrow < M ? i0 + lrow : M - 1;
+    const int e = lb.ex[p][gi];
+    const float sc = ldexpf(1.0f, -e);
+    if (half == 0) facA[lrow] = ldexpf(1.0f, e);
+    if (tid < LIN_BN) facB[tid] = lb.wfac[p][j0 + tid];
+    const float* ap = lb.x[p] + (size_t)gi * K + half * 16;
+    const char* bp = lb.wimg[p] + (size_t)tJ * KS * 16384 + tid * 16;
+    char* const a_dst = As + (half * 2) * 4096 + lrow * 16;
+    f32x4 av[4];
+    u32x4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        av[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+        bv[i] = *reinterpret_cast<const u32x4*>(bp + 4096 * i);
+    }
+    const int hi = lane >> 5, ln = lane & 31;
+    const char* fa_base = As + hi * 4096 + (wr * 64 + ln) * 16;   // k16 sub-stage s: + s * 8192; tile ti: + ti * 512; lo part: + 2048
+    const char* fb_base = Bs + hi * 4096 + (wc * 64 + ln) * 16;
+    for (int ks = 0; ks < KS; ++ks) {
+        __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+        for (int kgl = 0; kgl < 2; ++kgl) {
+            l16_h8 vh, vl;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float xn = av[2 * kgl + (c >> 2)][c & 3] * sc;   // exact: a power of two
+                const _Float16 h = (_Float16)xn;
+                vh[c] = h;
+                vl[c] = (_Float16)(xn - (float)h);
+            }
+            *reinterpret_cast<l16_h8*>(a_dst + kgl * 4096) = vh;
+            *reinterpret_cast<l16_h8*>(a_dst + kgl * 4096 + 2048) = vl;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Bs + 4096 * i + tid * 16) = bv[i];
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = *reinterpret_cast<const f32x4*>(ap + (ks + 1) * 32 + 4 * i);
+                bv[i] = *reinterpret_cast<const u32x4*>(bp + (size_t)(ks + 1) * 16384 + 4096 * i);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            l16_h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const char* pa = fa_base + s * 8192 + ti * 512;
+                const char* pb = fb_base + s * 8192 + ti * 512;
+                ah[ti] = *reinterpret_cast<const l16_h8*>(pa);
+                al[ti] = *reinterpret_cast<const l16_h8*>(pa + 2048);
+                bh[ti] = *reinterpret_cast<const l16_h8*>(pb);
+                bl[ti] = *reinterpret_cast<const l16_h8*>(pb + 2048);
+            }
+            // small terms first; every accumulator is touched again only after three other MFMAs (ds_gemm16_kernel's order)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+        }
+    }
+    // epilogue: y = acc * 2^e_m * 2^e_n (+ bias); lane (hi, ln) holds rows {(r&3) + 8(r>>2) + 4hi}, column ln of each 32x32 block
+    const float* __restrict__ bias = lb.bias[p];
+    float* __restrict__ Y = lb.y[p];
+    float bj[2], fbv[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int cj = wc * 64 + tj * 32 + ln;
+        fbv[tj] = facB[cj];
+        bj[tj] = bias ? bias[j0 + cj] : 0.f;
+    }
+    if (lb.qw) {   // quad-major rows (see linear_nt_kernel)
+        const int hw = lb.qh * lb.qw, wq = lb.qw >> 1, Lq = (lb.qh >> 1) * wq, Hh = N >> 5;
+        const unsigned b0 = (unsigned)i0 / (unsigned)hw, rem0 = (unsigned)i0 - b0 * (unsigned)hw;   // wave-uniform
+        float* yh[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) yh[tj] = Y + (size_t)((j0 + wc * 64 + tj * 32) >> 5) * Lq * 128 + ln;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const unsigned gr = (unsigned)(i0 + lr);
+                if ((int)gr >= M) continue;
+                unsigned b = b0, pp = rem0 + (unsigned)lr;
+                while (pp >= (unsigned)hw) { pp -= (unsigned)hw; ++b; }
+                const unsigned y = __umulhi(pp, lb.magic_w), x = pp - y * (unsigned)lb.qw;
+                const size_t roff = ((size_t)b * Hh * Lq + (size_t)((y >> 1) * wq + (x >> 1))) * 128 + ((y & 1) * 2 + (x & 1)) * 32;
+                const float fa = facA[lr];
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const float v = (acc[ti][tj][r] * fa) * fbv[tj];
+                    yh[tj][roff] = bias ? v + bj[tj] : v;
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int gr = i0 + lr;
+            if (gr >= M) continue;
+            const float fa = facA[lr];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const float v = (acc[ti][tj][r] * fa) * fbv[tj];
+                Y[(size_t)gr * N + j0 + wc * 64 + tj * 32 + ln] = bias ? v + bj[tj] : v;
+            }
+        }
+}
+
+extern "C" size_t casmtr_linear_split_prep_bytes(int N, int K) {
+    return (N > 0 && K > 0 && N % LIN_BN == 0 && K % LIN_BK == 0) ? (size_t)N * K * 4 + (size_t)N * 4 : 0;   // image (2 f16 per element), then fac[N]
+}
+
+extern "C" int casmtr_linear_split_prep(const float* w, void* prep, int N, int K, casmtr_stream_t stream) {
+    if (N <= 0 || K <= 0 || N % LIN_BN != 0 || K % LIN_BK != 0 || K > 256) return CASMTR_ERR_UNSUPPORTED;
+    char* img = reinterpret_cast<char*>(prep);
+    hipLaunchKernelGGL(lin_wprep_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, w, N, K, img, reinterpret_cast<float*>(img + (size_t)N * K * 4));
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
+                                       int nprob, int M, int N, int K, int h, int w_, int32_t* ex_ws, casmtr_stream_t stream) {
+    if (nprob <= 0 || M <= 0 || N <= 0) return 0;
+    if (nprob > LIN_MAXP || K <= 0 || K % LIN_BK != 0 || K > 256 || N % LIN_BN != 0 || !ex_ws) return CASMTR_ERR_UNSUPPORTED;
+    Linear16Batch lb{};
+    if (w_) {
+        if (h <= 0 || w_ <= 1 || (h & 1) || (w_ & 1) || M % (h * w_) != 0) return CASMTR_ERR_UNSUPPORTED;
+        if (!lin_magic((unsigned)w_, (unsigned)(h * w_), &lb.magic_w)) return CASMTR_ERR_UNSUPPORTED;
+        lb.qh = h; lb.qw = w_;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int nex = 0;
+    for (int i = 0; i < nprob; ++i) {
+        int same = -1;
+        for (int j = 0; j < i; ++j)
+            if (x[j] == x[i]) { same = j; break; }
+        if (same >= 0) lb.ex[i] = lb.ex[same];       // q / k / v of one block: k and v project the same tokens
+        else {
+            int* ex = ex_ws + (size_t)nex++ * M;
+            ProfScope ps(CASMTR_PROF_LINEAR_PREP, s, "lin_rowexp_kernel");
+            hipLaunchKernelGGL(lin_rowexp_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x[i], M, K, ex);
+            lb.ex[i] = ex;
+        }
+        lb.x[i] = x[i];
+        lb.wimg[i] = reinterpret_cast<const char*>(wprep[i]);
+        lb.wfac[i] = reinterpret_cast<const float*>(lb.wimg[i] + (size_t)N * K * 4);
+        lb.bias[i] = bias ? bias[i] : nullptr;
+        lb.y[i] = y[i];
+    }
+    CASMTR_CHECK_LAUNCH();
+    const int NIB = (M + LIN_BM - 1) / LIN_BM, NJB = N / LIN_BN;
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_LINEAR, linear16_kernel, dim3(NIB * NJB, nprob), dim3(256), 0, s, lb, M, N, K, NJB);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
 // =================================================================================================== token pyramid
 #define POOL_MAXT 4
 

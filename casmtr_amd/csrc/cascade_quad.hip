@@ -74,24 +74,13 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     const int chunk = (a.nitems + G - 1) / G, cnt = min(chunk, a.nitems - g * chunk);
     const int total = cnt > 0 ? a.B * cnt : 0, stride = (gridDim.x >> 3) * 2;
     int t = (blockIdx.x >> 3) * 2 + wave;
-    int* const ctr = a.ctr ? a.ctr + xcd : nullptr;
+    int* const ctr = a.ctr ? a.ctr + xcd * WORK_XCD_INTS : nullptr;
     // dynamic claiming: every wave of this XCD's share of the grid reports in once when it leaves; the last one re-zeroes the pair
     auto leave = [&]() {
-        if (ctr && lane == 0 && atomicAdd(ctr + 8, 1) == stride - 1) { atomicExch(ctr, 0); atomicExch(ctr + 8, 0); }
+        if (ctr && lane == 0) work_leave(ctr, stride);
     };
     if (g >= G || t >= total) { leave(); return; }
-    int t_claim = 0;       // lane 0: the item claimed behind the last prefetch (an atomic with return: valid once it has come back)
-    bool t_have = true;    // `t` holds the next item to prefetch (false: it is still in t_claim)
-    auto claim = [&]() {   // right behind a prefetch: the item after that one
-        if (ctr) {
-            if (lane == 0) t_claim = atomicAdd(ctr, 1) + 2 * stride;   // items 0 .. 2 stride - 1 are the waves' static first two
-            t_have = false;
-        } else t += stride;
-    };
-    auto next_t = [&]() {
-        if (!t_have) { t = __builtin_amdgcn_readfirstlane(t_claim); t_have = true; }
-        return t;
-    };
+    bool claim_pending = false;   // the item after the last prefetch has been claimed and not collected yet (then t == total)
     for (int i = lane; i < 2048; i += 64) ring[i] = 0.f;    // rows of a short last chunk that no DMA ever wrote must be finite
     lds_reads_done();
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
@@ -214,7 +203,15 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     t += stride;
     stage_in();
     sub_cur = sub_nx;
-    if (!regs_full && t < total) { prefetch(t); claim(); }
+    if (!regs_full && t < total) {
+        prefetch(t);
+        if (ctr) {   // the first claim is waited for on the spot (once per wave); items 0 .. 2 stride - 1 are the waves' static first two
+            int r0;
+            work_claim_issue(ctr, true, r0);
+            glds_wait<0>();
+            t = work_claimed(r0) + 2 * stride;
+        } else t += stride;
+    }
     int hcur = h0, ubuf = 0;   // head of the current unit, its query staging buffer
     issue_q(sub_cur.b, sub_cur.quadA, sub_cur.hasB, h0, 0);
     // results of the previous unit: stored right behind the next one's first DMA wait
@@ -249,6 +246,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
         const float* qcur = qst + ubuf * QBUF + s.qslot * 128 + (lane & 3) * 32;
         const int qsw = (lane & 3) >> 1;
         const int n3 = (s.ncells - 24 + 1) >> 1;          // DMA instructions of the short last chunk
+        int claim_ret = 0;                                // this unit's claim (work_claim_issue under chunk 2, collected behind chunk 3's wait)
         const int nrow3 = 4 * s.ncells - 96;              // its valid rows
         // ================================================================== K passes: logits of rows 64p .. 64p+63 for both query slots
         float relv[HAS_REL ? 2 : 1][2][4];
@@ -371,8 +369,19 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             if constexpr (c == 2) glds_wait_dyn(n3);
             else if constexpr (c == 3) { if (more) glds_wait<4>(); else glds_wait<0>(); }
             else glds_wait<4>();
+            if constexpr (c == 3) {   // the claim issued under chunk 2 is older than the (at most four) instructions still in flight
+                const int v = work_claimed(claim_ret);
+                if (claim_pending) { t = v + 2 * stride; claim_pending = false; }
+            }
             if constexpr (c == 2) {
-                if (!same && more_sub && !regs_full && next_t() < total) { prefetch(t); claim(); }   // issued behind the wait
+                const bool pf = !same && more_sub && !regs_full && t < total;
+                if (pf) prefetch(t);   // issued behind the wait
+                // ... and the item after it is claimed now, a whole unit before it is needed (dynamic schedule; unconditional statement)
+                work_claim_issue(ctr, pf && ctr != nullptr, claim_ret);
+                if (pf) {
+                    if (ctr) { claim_pending = true; t = total; }
+                    else t += stride;
+                }
             }
             const int nmm = c < 3 ? 16 : (nrow3 >> 1);   // valid row pairs of this chunk
             float vb[16];
@@ -465,7 +474,9 @@ extern "C" int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, co
     a.q = q; a.key = key; a.value = value; a.tp = topk_pos; a.rel = rel_pos; a.message = message; a.temp = temp;
     a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.H = nhead; a.nquads = (h0 / 2) * (w0 / 2); a.lq1 = (h1 / 2) * (w1 / 2);
     a.npr = (w0 / 2 + 1) / 2; a.nitems = (h0 / 2) * a.npr;
-    { const char* ev = getenv("CASMTR_CQ_ORDER"); a.colmajor = !(ev && ev[0] == 'r'); }
+    // item order inside an XCD's chunk.  With dynamic claiming (round 6) along the rows: 480 against 580 us per launch on smooth windows, the
+    // same on the bench's mix (profiles/r06_cq_fields.txt); the static schedule of rounds 3-5 measured the two orders alike.
+    { const char* ev = getenv("CASMTR_CQ_ORDER"); a.colmajor = ev ? ev[0] == 'c' : 0; }
     // heads per wave: the front end (positions, sharing decision, masks, DMA offsets) is amortised over them, but an XCD's L2 then
     // holds that many heads' window neighbourhoods at once (~1.3 MB each at 208 x 208 with 320 waves per XCD).  Measured (round 4):
     // isolated launches on perfectly smooth windows 519 -> 466 us with all 4 heads per wave; inside the bench step (windows from the

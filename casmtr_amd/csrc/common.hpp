@@ -9,6 +9,7 @@
 #define NEG_FILL (-1e9f)  // INF = 1e9 in coarse_matching.py:6 / cascade_matching.py:8
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace casmtr {
@@ -200,11 +201,43 @@ __device__ __forceinline__ float sum_over_slices8(float x) {
     return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
-// prof.hip.  Work counters of the persistent gather kernels (dynamic item claiming): -> 16 zeroed ints on the current device, [0..7] the
-// per-XCD claim counters, [8..15] the per-XCD exit counters.  The kernels leave them zero again (the last wave of an XCD to exit resets
-// its pair), so a slot needs no clearing launch; slots rotate (64 per device) so that launches in flight on different streams do not
-// share one.  nullptr on allocation failure (callers then use their static schedule).
+// prof.hip.  Work counters of the persistent gather kernels (dynamic item claiming): -> one slot of WORK_SLOT_INTS zeroed ints on the
+// current device: XCD x's claim counter at [x * WORK_XCD_INTS], its exit counter WORK_EXIT_OFF ints behind it.  EVERY COUNTER IN ITS OWN
+// 128-BYTE LINE: a line is owned by the L2 of the XCD whose waves use it and the atomics run at L2 speed; with the eight XCDs' counters
+// in one line the line ping-pongs between the eight L2s and each claim costs ~90 ns (cascade_quad_kernel: 2.0 ms instead of 0.6,
+// profiles/r06_cq_fields.txt).  The kernels leave the counters zero again (the last wave of an XCD to exit resets its pair), so a slot
+// needs no clearing launch; slots rotate (64 per device) so that launches in flight on different streams do not share one.  nullptr
+// when unavailable (allocation failure, a stream capture in progress at first use): callers then use their static schedule.
+#define WORK_XCD_INTS 64
+#define WORK_EXIT_OFF 32
+#define WORK_SLOT_INTS (8 * WORK_XCD_INTS)
 int* work_counters();
+// Claim (whole wave active, wave-uniform `doit`): lane 0 adds 1 to the counter, the pre-increment value arrives in `ret` ASYNCHRONOUSLY,
+// like a load: it is valid once a LATER s_waitcnt vmcnt(N) has passed with N <= the number of vector-memory operations issued behind
+// the claim (vmcnt retires in order); read it with work_claimed(ret) behind such a wait.  doit == false: the instruction runs with
+// EXEC = 0 and does nothing, so the statement is unconditional for the compiler.  Inline asm on purpose:
+//   (1) the compiler's atomic optimiser turns a uniform atomicAdd into "atomic, s_waitcnt vmcnt(0), v_readfirstlane" on the spot, which
+//       exposes the round trip and drains every LDS-DMA in flight;
+//   (2) to the compiler an asm output is valid at once.  `ret` must therefore be defined by this statement and consumed by
+//       work_claimed() in the SAME loop iteration with nothing else reading it: a loop-carried or conditionally defined variable gets
+//       copied (phi moves) a few instructions behind the atomic, before the data has arrived (seen in the first version; AGPRs as a
+//       mailbox make the allocator split the whole kernel's registers into VGPR + AGPR halves with ~900 copies).
+//       tools/check_quad_isa.py checks that no instruction touches the register between the two statements.
+__device__ __forceinline__ void work_claim_issue(int* ctr, bool doit, int& ret) {
+    const int m = __builtin_amdgcn_readfirstlane(doit ? 1 : 0);   // (the compiler cannot always prove `doit` uniform: pin it to an SGPR)
+    unsigned long long save;
+    const int zero = 0, one = 1;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %3, %4, %5 sc0\n\ts_mov_b64 exec, %1"
+                 : "=v"(ret), "=&s"(save) : "s"(m), "v"(zero), "v"(one), "s"(ctr) : "memory");
+}
+__device__ __forceinline__ int work_claimed(const int& ret) {   // lane 0's value, wave-uniform
+    int s;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(ret));
+    return s;
+}
+__device__ __forceinline__ void work_leave(int* ctr, int nwaves) {   // one lane per wave; the last of the XCD's nwaves waves re-zeroes the pair
+    if (atomicAdd(ctr + WORK_EXIT_OFF, 1) == nwaves - 1) { atomicExch(ctr, 0); atomicExch(ctr + WORK_EXIT_OFF, 0); }
+}
 extern int g_debug_flags;   // casmtr_debug_set(): phase-elimination switches for timing experiments (results become garbage)
 #define CASMTR_DBG_NO_DMA 1      // DMA kernels: do not issue / wait for the key and value row transfers
 #define CASMTR_DBG_NO_MATH 2     // DMA kernels: skip the per-stage LDS reads and arithmetic

@@ -10,6 +10,7 @@
 #include "../../include/casmtr_hip.h"
 
 namespace casmtr {
+// ---- work counters of the persistent gather kernels (dynamic item claiming, common.hpp)
 int* work_counters() {
     constexpr int NSLOT = 64;
     static int* base[CASMTR_MAX_DEVICES] = {nullptr};
@@ -18,12 +19,17 @@ int* work_counters() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return nullptr;
     int* p = __atomic_load_n(&base[dev], __ATOMIC_ACQUIRE);
     if (!p) {
-        if (hipMalloc(&p, sizeof(int) * 16 * NSLOT) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, sizeof(int) * 16 * NSLOT) != hipSuccess) { (void)hipFree(p); return nullptr; }   // synchronous, once per device
+        // (fails while a stream capture is in progress: the caller then runs its static schedule, and the next eager call allocates)
+        if (hipMalloc(&p, sizeof(int) * WORK_SLOT_INTS * NSLOT) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, sizeof(int) * WORK_SLOT_INTS * NSLOT) != hipSuccess) {   // synchronous, once per device
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
         int* expect = nullptr;
         if (!__atomic_compare_exchange_n(&base[dev], &expect, p, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { (void)hipFree(p); p = expect; }
     }
-    return p + 16 * (__atomic_fetch_add(&seq[dev], 1u, __ATOMIC_RELAXED) % NSLOT);
+    return p + WORK_SLOT_INTS * (__atomic_fetch_add(&seq[dev], 1u, __ATOMIC_RELAXED) % NSLOT);
 }
 
 int g_debug_flags = 0;
@@ -92,7 +98,7 @@ static const char* kNames[CASMTR_PROF_COUNT] = {
     "qta_coarsest[av]", "qta_fine_level[lists<=64]", "cascade_attn", "window_match", "nms_select",
     "layout", "window_warp_idx", "linear_nt", "token_pool", "qta_coarsest_level",
     "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "dual_softmax_split_prepass", "dual_softmax_fix",
-    "dual_softmax_gemm_edge"};
+    "dual_softmax_gemm_edge", "linear_split_prep"};
 
 static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {

@@ -295,7 +295,7 @@ enum {
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
     CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED,
-    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_DS_SPLIT, CASMTR_PROF_DS_FIX, CASMTR_PROF_DS_GEMM_EDGE, CASMTR_PROF_COUNT
+    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_DS_SPLIT, CASMTR_PROF_DS_FIX, CASMTR_PROF_DS_GEMM_EDGE, CASMTR_PROF_LINEAR_PREP, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
 /* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).

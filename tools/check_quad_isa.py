@@ -21,6 +21,53 @@ NO_COMPILER_VMEM = {"fine_quad_kernel"}          # no vector load / vmcnt wait o
 SPILL_EXEMPT = re.compile(r"coarse_tile_kernelILi16E")   # S > 704 keys: 144 VGPRs at 3 waves per SIMD, spill-free today but not promised
 
 
+def check_claims(name, lines):
+    """Dynamic item claiming (common.hpp work_claim_issue / work_claimed): the atomic's return value arrives asynchronously in a VGPR
+    that the compiler believes valid at once.  Between the inline-asm `global_atomic_add vX, ... sc0` and the inline-asm
+    `v_readfirstlane_b32 sY, vX` that consumes it, NO instruction may mention vX (a copy would read it before the data has arrived) and
+    control may not leave the straight line (a label or a backward branch would mean the register is live around the loop).  The
+    first `s_waitcnt vmcnt` in between is the hand-counted wait that covers the claim: it must be there."""
+    problems = []
+    in_asm = False
+    i = 0
+    while i < len(lines):
+        l = lines[i]
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        m = re.match(r"\s*global_atomic_add (v\d+), v\d+, v\d+, s\[\d+:\d+\] sc0\s*$", l.split(";")[0]) if in_asm else None
+        if m:
+            reg = m.group(1)
+            waited = False
+            j = i + 1
+            asm2 = True
+            while j < len(lines):
+                c = lines[j].split(";")[0]
+                if "#ASMSTART" in lines[j]:
+                    asm2 = True
+                elif "#ASMEND" in lines[j]:
+                    asm2 = False
+                if re.match(rf"\s*v_readfirstlane_b32 s\d+, {reg}\s*$", c) and asm2:
+                    break
+                if re.search(r"s_waitcnt.*vmcnt", c):
+                    waited = True
+                if re.search(rf"\b{reg}\b", c) or re.search(rf"\bv\[(\d+):(\d+)\]", c) and any(
+                        int(a) <= int(reg[1:]) <= int(b) for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", c)):
+                    problems.append(f"{name}: {reg} (a claim in flight) is touched before its v_readfirstlane: {c.strip()}")
+                    break
+                if re.match(r"\s*s_endpgm", c):
+                    problems.append(f"{name}: claim in {reg} is never collected")
+                    break
+                j += 1
+            else:
+                problems.append(f"{name}: claim in {reg} is never collected")
+            if j < len(lines) and not waited and not any("touched" in p_ or "never" in p_ for p_ in problems):
+                problems.append(f"{name}: no vmcnt wait between the claim in {reg} and its v_readfirstlane")
+        i += 1
+    return problems
+
+
 def check(asm_text, kernel, n_expected):
     problems = []
     names = sorted(set(re.findall(rf"^(_Z\d+{kernel}\w+):", asm_text, re.M)))
@@ -49,6 +96,7 @@ def check(asm_text, kernel, n_expected):
                 problems.append(f"{name}: compiler-visible vector load / vmcnt wait in a hand-counted DMA kernel: {code.strip()}")
         if ndma == 0:
             problems.append(f"{name}: no LDS-DMA instructions found")
+        problems += check_claims(name, lines)
         meta = asm_text.split(f".name:           {name}", 1)
         if len(meta) == 2:
             m = re.search(r"\.vgpr_spill_count:\s*(\d+)", meta[1])
