@@ -46,6 +46,7 @@ struct CasQArgs {
                            // out with a fixed stride: the waves of an XCD then always work on one compact front of ~2 x (waves per XCD)
                            // consecutive items (the window boxes of a front share the L2), and a wave that drew expensive items (incoherent
                            // windows: 25.6 KB straight from HBM) simply takes fewer
+    int claim;             // consecutive items per claim (an L2 atomic on one address costs ~16 ns: see fine_quad.hip)
 };
 
 struct Sub {   // one sub-item: the candidate rows of `ncells` cells against nq query quads (all wave-uniform)
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
     };
     if (g >= G || t >= total) { leave(); return; }
     bool claim_pending = false;   // the item after the last prefetch has been claimed and not collected yet (then t == total)
+    int rem = 0;                  // items left in the claimed run behind t
     for (int i = lane; i < 2048; i += 64) ring[i] = 0.f;    // rows of a short last chunk that no DMA ever wrote must be finite
     lds_reads_done();
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             int r0;
             work_claim_issue(ctr, true, r0);
             glds_wait<0>();
-            t = work_claimed(r0) + 2 * stride;
+            t = work_claimed(r0) * a.claim + 2 * stride;
+            rem = a.claim - 1;
         } else t += stride;
     }
     int hcur = h0, ubuf = 0;   // head of the current unit, its query staging buffer
@@ -371,16 +374,17 @@ __global__ __launch_bounds__(128, (HAS_REL ? 2 : 3)) void cascade_quad_kernel(co
             else glds_wait<4>();
             if constexpr (c == 3) {   // the claim issued under chunk 2 is older than the (at most four) instructions still in flight
                 const int v = work_claimed(claim_ret);
-                if (claim_pending) { t = v + 2 * stride; claim_pending = false; }
+                if (claim_pending) { t = v * a.claim + 2 * stride; rem = a.claim - 1; claim_pending = false; }
             }
             if constexpr (c == 2) {
                 const bool pf = !same && more_sub && !regs_full && t < total;
                 if (pf) prefetch(t);   // issued behind the wait
                 // ... and the item after it is claimed now, a whole unit before it is needed (dynamic schedule; unconditional statement)
-                work_claim_issue(ctr, pf && ctr != nullptr, claim_ret);
+                work_claim_issue(ctr, pf && ctr != nullptr && rem == 0, claim_ret);
                 if (pf) {
-                    if (ctr) { claim_pending = true; t = total; }
-                    else t += stride;
+                    if (!ctr) t += stride;
+                    else if (rem > 0) { ++t; --rem; }
+                    else { claim_pending = true; t = total; }
                 }
             }
             const int nmm = c < 3 ? 16 : (nrow3 >> 1);   // valid row pairs of this chunk
@@ -485,6 +489,7 @@ extern "C" int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, co
     // (XCD <-> head, the round-3 mapping).
     a.hw = 1;
     { const char* ev = getenv("CASMTR_CQ_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters(); }
+    { const char* ev = getenv("CASMTR_CQ_CLAIM"); a.claim = ev && atoi(ev) > 0 ? atoi(ev) : 1; }   // 1 / 2 / 4 / 8: 495 / 503 / 511 / 540 us (12 % random windows)
     { const char* ev = getenv("CASMTR_CQ_HEADS_PER_WAVE"); const int v = ev ? atoi(ev) : 0; if (v >= 1 && v <= nhead && nhead % v == 0 && (8 % (nhead / v)) == 0) a.hw = v; }
     return rel_pos ? launch_cas_quad<true>(a, (hipStream_t)stream) : launch_cas_quad<false>(a, (hipStream_t)stream);
 }

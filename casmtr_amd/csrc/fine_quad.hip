@@ -56,6 +56,11 @@ struct FineQArgs {
     float temp, w_level;
     int topk, B, h0, w0, h1, w1, H, Kp, nquads, lq1;
     unsigned div_magic;      // ceil(2^32 / (w1/2)): p / (w1/2) == umulhi(p, div_magic) for p < 2^22 (0: w1/2 == 1)
+    int* ctr;                // nullable: work_counters() -- items beyond a wave's first two are claimed (dynamic schedule), not dealt out
+    int claim;               // items per claim (consecutive): one L2 atomic on one address costs ~16 ns, the finest level hands out an item
+                             // every 11 ns per XCD -- with one item per claim the launch took 364 instead of 235 us (profiles/r06_dyn_ab.txt)
+    unsigned magic_chunk, magic_last, magic_wq;   // n / d == umulhi(n, magic) for d = items per XCD chunk (all but the last / the last chunk) and
+                                                  // d = w0 / 2; 0: d == 1
     int xflags;              // experiment switches (CASMTR_FQ_FLAGS): 1 nt loads of the side streams, 2 nt stores, 4 sc1 stores, 8 one K/V slice for all pairs, 16 staggered start
 };
 
@@ -277,7 +282,11 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     const int chunk = (Lq + G - 1) / G, cnt = min(chunk, Lq - g * chunk);
     const int total = cnt > 0 ? a.B * cnt : 0, stride = (gridDim.x >> 3) * 2;
     const int t = (blockIdx.x >> 3) * 2 + wave;
-    if (g >= G || t >= total) return;
+    int* const ctr = a.ctr ? a.ctr + xcd * WORK_XCD_INTS : nullptr;
+    if (g >= G || t >= total) {
+        if (ctr && lane == 0) work_leave(ctr, stride);
+        return;
+    }
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(ring));
     const int un = lane & 7;
     // DMA source offset inside a parent's 512-byte run.  Row r = 8 j + lane / 8 of a pass (j = DMA instruction 0..7); physical unit
@@ -296,21 +305,19 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
 
     // ---- per-item front end, one item ahead: global -> LDS staging (prefetch, DMA), staging -> DMA offsets (stage_in)
     struct Item { int b, quad, l00; };                  // pair, quad, first child's token (child f -> l00 + (f>>1)*w0 + (f&1))
-    int cb = t / cnt, cq = t % cnt, cy = (g * chunk + cq) / wq, cx = (g * chunk + cq) % wq;
-    const int sy = stride / wq, sx = stride % wq;
-    auto take = [&](Item& it) {   // -> false when the wave's list is exhausted
-        if (cb >= a.B) return false;
-        it.b = cb; it.quad = g * chunk + cq; it.l00 = 2 * cy * a.w0 + 2 * cx;
-        cq += stride;
-        if (cq >= cnt) {
-            while (cq >= cnt) { cq -= cnt; ++cb; }
-            cy = (g * chunk + cq) / wq; cx = (g * chunk + cq) % wq;
-        } else {
-            cy += sy; cx += sx;
-            if (cx >= wq) { cx -= wq; ++cy; }
-        }
-        return true;
+    // Item tt of this XCD's list: pair tt / cnt, quad g * chunk + tt % cnt.  The wave's first two items are static (its index, + stride);
+    // from the third on they are either dealt out with that stride (ctr == nullptr) or CLAIMED from the XCD's counter: the waves of an
+    // XCD then work on one compact front of consecutive items whatever their individual speeds (cascade_quad.hip has the measurements).
+    const unsigned mcnt = g == G - 1 ? a.magic_last : a.magic_chunk;
+    auto item_of = [&](int tt, Item& it) {
+        const unsigned ut = (unsigned)__builtin_amdgcn_readfirstlane(tt);
+        const unsigned b = mcnt ? __umulhi(ut, mcnt) : ut;
+        const unsigned quad = (unsigned)(g * chunk) + (ut - b * (unsigned)cnt);
+        const unsigned cy = a.magic_wq ? __umulhi(quad, a.magic_wq) : quad, cx = quad - cy * (unsigned)wq;
+        it.b = (int)b; it.quad = (int)quad; it.l00 = (int)(2 * cy * (unsigned)a.w0 + 2 * cx);
     };
+    int tn = t + stride;   // the item after it_nx
+    int rem = 0;           // items left in the claimed run behind tn
     if (a.xflags & 16) {   // timing experiment: the waves of a CU start up to one item period apart
         const int k = ((int)(blockIdx.x >> 3) % 5) * 2 + wave;
         for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(11);
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     //  step in alternating runs on one box.  The extra 8-16 instructions sit in front of the K rows in the in-order return queue.)
 
     Item it_cur{}, it_nx{};
-    take(it_cur);
+    item_of(t, it_cur);
     prefetch(it_cur, 0);
     glds_wait<0>();
     stage_in(0);
@@ -456,9 +463,11 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     };
     issue(0, I0{}, I0{}, it_cur.b);
     issue(0, I0{}, I1{}, it_cur.b);
-    bool more = take(it_nx);
+    bool more = tn < total;
+    if (more) item_of(tn, it_nx);
     for (;;) {
         const int b = it_cur.b, l00 = it_cur.l00, bn = it_nx.b;
+        int claim_ret = 0, claimed = 0;   // this item's claim (the item after it_nx): issued in K pass 0, collected behind the first V wait
         const float* qs = stg + cbuf * STG;
         const int* t2 = reinterpret_cast<const int*>(qs + 128);
         // ================================================================== K passes: logits of candidates 64p .. 64p+63
@@ -469,6 +478,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             if constexpr (p == 0) {
                 flush();
                 if (more) prefetch(it_nx, cbuf ^ 1);   // lands under this item's K pass and softmax; consumed at its chunk NV - 2
+                work_claim_issue(ctr, more && ctr != nullptr && rem == 0, claim_ret);   // (unconditional statement; EXEC = 0 unless a run ends)
                 acc_cur = a.acc_in ? qs[160 + (lane & 31)] : 0.f;   // final[parent] of the item for d = lane % 32 (:277)
             }
             f32x4 qa[8], kr[8];   // operand A: lane l holds q[child l%4][d]; operand B: this lane's candidate row
@@ -526,6 +536,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
             // in flight behind chunk c: chunk c + 1 (or the next item's first K chunk) = 4 instructions; the staging DMA of the next
             // item is older than every V chunk, so it has landed behind the first of these waits
             if (c + 1 < NV || more) glds_wait<4>(); else glds_wait<0>();
+            if constexpr (c == 0) claimed = work_claimed(claim_ret);   // the claim is older than the eight instructions issued behind it
             if constexpr (c == NV - 2) {
                 if (more) stage_in(cbuf ^ 1);   // every chunk of this item has been issued: the offsets become the next item's
             }
@@ -561,10 +572,15 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
         }
         if (!more) break;
         it_cur = it_nx; cbuf ^= 1;
-        more = take(it_nx);
+        if (!ctr) tn += stride;
+        else if (rem > 0) { ++tn; --rem; }
+        else { tn = 2 * stride + claimed * a.claim; rem = a.claim - 1; }   // counter value c = items 2 stride + c claim .. + claim - 1
+        more = tn < total;
+        if (more) item_of(tn, it_nx);
     }
     glds_wait<0>();
     flush();
+    if (ctr && lane == 0) work_leave(ctr, stride);
 }
 
 template <int NPASS, bool EXACT, bool FULL>
@@ -638,6 +654,26 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
     const unsigned d = (unsigned)(w1 / 2);
     a.div_magic = d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u;
     { const char* ev = getenv("CASMTR_FQ_FLAGS"); a.xflags = ev ? atoi(ev) : 0; }
+    {   // item index -> (pair, quad) and quad -> (row, column) by multiply-high: exact for every index the kernel can meet (else: static schedule)
+        const int G = 8 / H, chunk = (a.nquads + G - 1) / G, last = a.nquads - (G - 1) * chunk;
+        const unsigned long long nmax = (unsigned long long)B * (unsigned long long)(chunk > 0 ? chunk : 1) + 2;
+        auto magic = [](unsigned d, unsigned long long nmax_, unsigned* m) {   // n / d == umulhi(n, m) for n <= nmax_ (m = 0: d == 1)
+            if (d <= 1) { *m = 0; return true; }
+            const unsigned long long mm = (0x100000000ull + d - 1) / d, e = mm * d - 0x100000000ull;
+            if (mm > 0xFFFFFFFFull || nmax_ * e >= 0x100000000ull) return false;
+            *m = (unsigned)mm;
+            return true;
+        };
+        const bool ok = magic((unsigned)chunk, nmax, &a.magic_chunk) && magic((unsigned)(last > 0 ? last : 1), nmax, &a.magic_last) &&
+                        magic((unsigned)(w0 / 2), (unsigned long long)a.nquads + 1, &a.magic_wq);
+        if (!ok) return CASMTR_ERR_UNSUPPORTED;   // (grids of more than ~10^5 quads per XCD chunk: no shipped configuration)
+        const char* ev = getenv("CASMTR_FQ_DYNAMIC");
+        a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters();
+        const char* ec = getenv("CASMTR_FQ_CLAIM");
+        // isolated launches, B = 8 (profiles/r06_dyn_ab.txt): finest level static 211-236 us, 1 / 2 / 4 / 8 / 16 items per claim 360 / 225 /
+        // 208-220 / 215-220 / 232-262; middle level static 112-126, 118 / 108-111 / 111-120 / 124-132 / 164-175
+        a.claim = ec && atoi(ec) > 0 ? atoi(ec) : (K <= 64 ? 4 : 2);
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool full = K == 64 || K == 128;
     if (topk > 0) {

@@ -34,6 +34,8 @@ struct WPairArgs {
     int64_t* next_idx;      // [B, h0*w0]
     float sqrtC, inv_sqrtC, T, invT;
     int B, h0, w0, h1, w1, nquads, npr, nitems;   // npr = pair items per quad row, nitems = pair items per image pair
+    int* ctr;               // nullable: work_counters() -- items beyond a wave's first two are claimed, not dealt out (see cascade_quad.hip)
+    int claim;              // consecutive items per claim
 };
 
 struct WSub {   // one sub-item (all wave-uniform): `ncells` box cells against nq query quads; slot 1's quad is the right-hand neighbour
@@ -60,7 +62,13 @@ __global__ __launch_bounds__(128, 2) void window_match_pair_kernel(const WPairAr
     const int cnt = min(chunk, a.nitems - xcd * chunk);
     const int total = cnt > 0 ? a.B * cnt : 0, stride = (gridDim.x >> 3) * 2;
     int t = (blockIdx.x >> 3) * 2 + wave;
-    if (t >= total) return;
+    int* const ctr = a.ctr ? a.ctr + xcd * WORK_XCD_INTS : nullptr;
+    if (t >= total) {
+        if (ctr && lane == 0) work_leave(ctr, stride);
+        return;
+    }
+    bool claim_pending = false;   // the item after the last prefetch has been claimed and not collected yet (then t == total)
+    int rem = 0;                  // items left in the claimed run behind t
     const unsigned buf0_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(buf0));
     const unsigned buf1_lds = __builtin_amdgcn_readfirstlane(lds_byte_addr(buf1));
     const int sl8 = lane >> 3, un = lane & 7;
@@ -237,12 +245,22 @@ __global__ __launch_bounds__(128, 2) void window_match_pair_kernel(const WPairAr
     sub_cur = sub_nx;
     put_queries();
     int cnd[2] = {cnd_nx[0], cnd_nx[1]}, mkv[2] = {mk_nx[0], mk_nx[1]}, mqv = mq_nx;
-    if (!regs_full && t < total) { prefetch(t); t += stride; }
+    if (!regs_full && t < total) {
+        prefetch(t);
+        if (ctr) {   // the first claim is waited for on the spot (once per wave); items 0 .. 2 stride - 1 are the waves' static first two
+            int r0;
+            work_claim_issue(ctr, true, r0);
+            glds_wait<0>();
+            t = work_claimed(r0) * a.claim + 2 * stride;
+            rem = a.claim - 1;
+        } else t += stride;
+    }
     issue(std::integral_constant<int, 0>{}, sub_cur);
     for (;;) {
         const WSub s = sub_cur;
         const bool more = regs_full || pendB;          // another sub-item follows (its item's identity is in the prefetch registers)
         const int n1 = s.ncells > KW ? 7 : 5;
+        int claim_ret = 0;   // this sub-item's claim: issued under its last stage, collected at its end
         const float* qp = qn + s.qslot * 4 * QS + (lane & 3) * QS;
         f32x4 acc[2][2];
 #pragma unroll
@@ -265,7 +283,14 @@ __global__ __launch_bounds__(128, 2) void window_match_pair_kernel(const WPairAr
             }
             if constexpr (st == 0) flush();
             if constexpr (st == NS - 1) {
-                if (more && !regs_full && t < total) { prefetch(t); t += stride; }   // behind the wait: a whole sub-item ahead of stage_in
+                const bool pf = more && !regs_full && t < total;
+                if (pf) prefetch(t);   // behind the wait: a whole sub-item ahead of stage_in
+                work_claim_issue(ctr, pf && ctr != nullptr && rem == 0, claim_ret);   // dynamic schedule: the next run of items (unconditional statement)
+                if (pf) {
+                    if (!ctr) t += stride;
+                    else if (rem > 0) { ++t; --rem; }
+                    else { claim_pending = true; t = total; }
+                }
             }
             const char* bp = reinterpret_cast<const char*>(p ? buf1 : buf0);
             f32x4 kr[8];          // operand B: this lane's candidate row chunk
@@ -376,6 +401,14 @@ __global__ __launch_bounds__(128, 2) void window_match_pair_kernel(const WPairAr
         }
         pend_sub = s; have_pend = true;
         lds_reads_done();
+        if (claim_pending) {
+            // the claim must be back before the loop's back edge (the compiler may copy loop-carried registers there).  Everything older --
+            // the next sub-item's stage 0, this prefetch's loads -- was issued before the softmax above and is needed at the top anyway.
+            glds_wait<0>();
+            t = work_claimed(claim_ret) * a.claim + 2 * stride;
+            rem = a.claim - 1;
+            claim_pending = false;
+        }
         if (!more) break;
         put_queries();
         cnd[0] = cnd_nx[0]; cnd[1] = cnd_nx[1]; mkv[0] = mk_nx[0]; mkv[1] = mk_nx[1]; mqv = mq_nx;
@@ -383,6 +416,7 @@ __global__ __launch_bounds__(128, 2) void window_match_pair_kernel(const WPairAr
     }
     glds_wait<0>();
     flush();
+    if (ctr && lane == 0) work_leave(ctr, stride);
 }
 
 template <int C, bool RECIP>
@@ -414,5 +448,7 @@ int casmtr_window_match_pair(const float* fq, const float* fk, const int64_t* tp
     a.sqrtC = (float)sqrt((double)C); a.inv_sqrtC = 1.0f / a.sqrtC; a.T = T; a.invT = 1.0f / T;
     a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.nquads = (h0 / 2) * (w0 / 2);
     a.npr = (w0 / 2 + 1) / 2; a.nitems = (h0 / 2) * a.npr;
+    { const char* ev = getenv("CASMTR_WP_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters(); }
+    { const char* ev = getenv("CASMTR_WP_CLAIM"); a.claim = ev && atoi(ev) > 0 ? atoi(ev) : 1; }
     return C == 128 ? launch_wm_pair<128, true>(a, s) : launch_wm_pair<64, true>(a, s);
 }

@@ -80,7 +80,8 @@ def check(asm_text, kernel, n_expected):
             problems.append(f"{name}: scratch instructions present (register spills)")
         in_asm = False
         ndma = 0
-        for l in lines:
+        exit_atomic = -100   # line of the last compiler-generated exit-counter atomic (common.hpp work_leave: outside the item loop, at a wave's exit)
+        for li, l in enumerate(lines):
             if "#ASMSTART" in l:
                 in_asm = True
             elif "#ASMEND" in l:
@@ -92,6 +93,10 @@ def check(asm_text, kernel, n_expected):
                 ndma += 1
                 if not in_asm:
                     problems.append(f"{name}: LDS-DMA outside inline asm")
+            elif not in_asm and re.match(r"\s*global_atomic_add v\d+, v\d+, v\d+, s\[\d+:\d+\] offset:128 sc0", code):
+                exit_atomic = li
+            elif kernel in NO_COMPILER_VMEM and not in_asm and "vmcnt" in code and li - exit_atomic <= 8:
+                pass   # the wait for the exit counter's return value
             elif kernel in NO_COMPILER_VMEM and not in_asm and (re.match(r"\s*(global|buffer|flat)_load", code) or "vmcnt" in code):
                 problems.append(f"{name}: compiler-visible vector load / vmcnt wait in a hand-counted DMA kernel: {code.strip()}")
         if ndma == 0:

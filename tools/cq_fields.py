@@ -69,9 +69,10 @@ for name in ("smooth", "mix6", "mix12", "mix25", "random"):
                 ref = m
             same = torch.equal(ref, m)
             print(f"{name:7s} order {order} dynamic {dyn}: {timeit(tp):7.1f} us per launch   bit-equal to the first variant: {same}", flush=True)
-    for wpx in (256, 384, 448):
-        os.environ["CASMTR_CQ_ORDER"] = "c"
-        os.environ["CASMTR_CQ_DYNAMIC"] = "1"
-        os.environ["CASMTR_CQ_WAVES_PER_XCD"] = str(wpx)
-        print(f"{name:7s} order c dynamic 1, {wpx} waves per XCD: {timeit(tp):7.1f} us per launch", flush=True)
-    os.environ.pop("CASMTR_CQ_WAVES_PER_XCD", None)
+    os.environ["CASMTR_CQ_ORDER"] = "r"
+    os.environ["CASMTR_CQ_DYNAMIC"] = "1"
+    for claim in (1, 2, 4, 8):
+        os.environ["CASMTR_CQ_CLAIM"] = str(claim)
+        print(f"{name:7s} order r dynamic 1, {claim} item(s) per claim: {timeit(tp):7.1f} us per launch   bit-equal: {torch.equal(ref, run(tp))}", flush=True)
+    os.environ.pop("CASMTR_CQ_CLAIM", None)
+    os.environ.pop("CASMTR_CQ_ORDER", None)
