@@ -191,8 +191,10 @@ extern "C" int casmtr_linear_quads_fwd(const float* const* x, const float* const
 // ~1e-7 |x||w|, tests/test_gpu_callers.py).  Default stays the exact chain (casmtr_linear_fwd); callers opt in (ops.linear_multi(gemm=)).
 //   * weights: split once into the GEMM's tile image (casmtr_linear_split_prep; cached by the caller per weight tensor):
 //       img[jb = n / 128][ks = k / 32][kg = (k / 8) % 4][part hi | lo][row n % 128][8 f16]  (16 KB per (jb, ks)), fac[n] = 2^e_n
-//   * activations: one wave per row finds the exponent (lin_rowexp_kernel: M ints); the GEMM reads the fp32 rows itself and splits them on
-//     the way into LDS (no activation image in HBM: the kernel is bound by reading x and writing y, 64 flop per byte at K = N = 256)
+//   * activations: the GEMM reads the fp32 rows itself, finds every row's exponent in a first pass over its 128 x K tile (the second pass,
+//     the k-loop, re-reads the tile from the L2 it has just been pulled into) and splits the rows on the way into LDS: no activation
+//     image and no exponent array in HBM -- the kernel is bound by reading x and writing y (64 flop per byte at K = N = 256).  (A
+//     separate exponent pass, one wave per row, cost 1.2 ms per step next to 3.9 ms of GEMMs: one more read of every activation.)
 //   * linear16_kernel: linear_nt_kernel's structure (128 x 128 tile, 4 waves x 64 x 64, next k-chunk prefetched into registers under the
 //     MFMAs of the current one), 12 MFMAs per wave and 16 channels, small terms first; epilogue acc * 2^e_m * 2^e_n + bias, token-major or
 //     quad-major rows exactly as linear_nt_kernel.
@@ -200,7 +202,6 @@ typedef _Float16 l16_h8 __attribute__((ext_vector_type(8)));
 
 struct Linear16Batch {
     const float* x[LIN_MAXP];
-    const int* ex[LIN_MAXP];        // [M] row exponents of x_p
     const char* wimg[LIN_MAXP];     // weight tile image
     const float* wfac[LIN_MAXP];    // [N] 2^e_n
     const float* bias[LIN_MAXP];    // nullable
@@ -208,21 +209,6 @@ struct Linear16Batch {
     int qh, qw;
     unsigned magic_w;
 };
-
-// wave per row: e = exponent that puts the row's largest |element| into [512, 1024) (ds_rownorm_kernel's rule)
-__global__ __launch_bounds__(256) void lin_rowexp_kernel(const float* __restrict__ x, int M, int K, int* __restrict__ ex) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float* p = x + (size_t)row * K;
-    float mx = 0.f;
-    for (int c = lane * 4; c < K; c += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    mx = wave_max_f32(mx);
-    if (lane == 0) ex[row] = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
-}
 
 // workgroup per weight row: exponent, factor, split into the tile image (N x K <= 64 K elements: latency-bound, run once per weight)
 __global__ __launch_bounds__(64) void lin_wprep_kernel(const float* __restrict__ w, int N, int K, char* __restrict__ img, float* __restrict__ fac) {
@@ -267,11 +253,22 @@ __global__ __launch_bounds__(256, 3) void linear16_kernel(const Linear16Batch lb
     // activations: thread <-> (row tid / 2, 16 channels of the chunk): two kg planes of the image
     const int lrow = tid >> 1, half = tid & 1;
     const int gi = i0 + lrow < M ? i0 + lrow : M - 1;
-    const int e = lb.ex[p][gi];
+    const float* ap = lb.x[p] + (size_t)gi * K + half * 16;
+    // first pass: the row's largest |element| -> the exponent that puts it into [512, 1024) (ds_rownorm_kernel's rule); the two threads
+    // of a row hold one half of every 32-channel chunk each
+    float mx = 0.f;
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + ks * 32 + 4 * i);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    }
+    mx = fmaxf(mx, dpp_f32<0xB1>(mx));   // lane ^ 1
+    const int e = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;
     const float sc = ldexpf(1.0f, -e);
     if (half == 0) facA[lrow] = ldexpf(1.0f, e);
     if (tid < LIN_BN) facB[tid] = lb.wfac[p][j0 + tid];
-    const float* ap = lb.x[p] + (size_t)gi * K + half * 16;
     const char* bp = lb.wimg[p] + (size_t)tJ * KS * 16384 + tid * 16;
     char* const a_dst = As + (half * 2) * 4096 + lrow * 16;
     f32x4 av[4];
@@ -401,9 +398,9 @@ extern "C" int casmtr_linear_split_prep(const float* w, void* prep, int N, int K
 }
 
 extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
-                                       int nprob, int M, int N, int K, int h, int w_, int32_t* ex_ws, casmtr_stream_t stream) {
+                                       int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream) {
     if (nprob <= 0 || M <= 0 || N <= 0) return 0;
-    if (nprob > LIN_MAXP || K <= 0 || K % LIN_BK != 0 || K > 256 || N % LIN_BN != 0 || !ex_ws) return CASMTR_ERR_UNSUPPORTED;
+    if (nprob > LIN_MAXP || K <= 0 || K % LIN_BK != 0 || K > 256 || N % LIN_BN != 0) return CASMTR_ERR_UNSUPPORTED;
     Linear16Batch lb{};
     if (w_) {
         if (h <= 0 || w_ <= 1 || (h & 1) || (w_ & 1) || M % (h * w_) != 0) return CASMTR_ERR_UNSUPPORTED;
@@ -411,25 +408,13 @@ extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const*
         lb.qh = h; lb.qw = w_;
     }
     hipStream_t s = (hipStream_t)stream;
-    int nex = 0;
     for (int i = 0; i < nprob; ++i) {
-        int same = -1;
-        for (int j = 0; j < i; ++j)
-            if (x[j] == x[i]) { same = j; break; }
-        if (same >= 0) lb.ex[i] = lb.ex[same];       // q / k / v of one block: k and v project the same tokens
-        else {
-            int* ex = ex_ws + (size_t)nex++ * M;
-            ProfScope ps(CASMTR_PROF_LINEAR_PREP, s, "lin_rowexp_kernel");
-            hipLaunchKernelGGL(lin_rowexp_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x[i], M, K, ex);
-            lb.ex[i] = ex;
-        }
         lb.x[i] = x[i];
         lb.wimg[i] = reinterpret_cast<const char*>(wprep[i]);
         lb.wfac[i] = reinterpret_cast<const float*>(lb.wimg[i] + (size_t)N * K * 4);
         lb.bias[i] = bias ? bias[i] : nullptr;
         lb.y[i] = y[i];
     }
-    CASMTR_CHECK_LAUNCH();
     const int NIB = (M + LIN_BM - 1) / LIN_BM, NJB = N / LIN_BN;
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_LINEAR, linear16_kernel, dim3(NIB * NJB, nprob), dim3(256), 0, s, lb, M, N, K, NJB);
     CASMTR_CHECK_LAUNCH();

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(128, (NPASS == 1 ? 4 : 3)) void fine_quad_kernel(co
     const int vL = vg(L), vHD = vg(HD), vw0 = vg(a.w0), vtopk = vg(a.topk), vH = vg(H), vh = vg(h);
     const float vwl = vg(a.w_level);
     auto flush = [&]() {
-        if (have_pend) {
+        if (have_pend && !(a.xflags & 32)) {   // (32: timing experiment -- no result stores at all)
             const int hi = lane >> 5;
             const float vA = hi ? pend[2] : pend[0], vB = hi ? pend[3] : pend[1];
             const size_t o = ((size_t)pend_b * vL + pend_l00 + hi * vw0) * vHD + vh * 32 + (lane & 31);

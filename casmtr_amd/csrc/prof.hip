@@ -98,7 +98,7 @@ static const char* kNames[CASMTR_PROF_COUNT] = {
     "qta_coarsest[av]", "qta_fine_level[lists<=64]", "cascade_attn", "window_match", "nms_select",
     "layout", "window_warp_idx", "linear_nt", "token_pool", "qta_coarsest_level",
     "glue(dwconv3x3_tokens, layer_norm)", "qta_fine_level[lists>64]", "dual_softmax_split_prepass", "dual_softmax_fix",
-    "dual_softmax_gemm_edge", "linear_split_prep"};
+    "dual_softmax_gemm_edge"};
 
 static void prof_reset(unsigned mask) {
     for (int i = 0; i < CASMTR_PROF_COUNT; ++i) {

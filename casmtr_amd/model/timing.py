@@ -8,11 +8,11 @@ from .casmtr4c import CasMTR4c, outdoor_2c_config, outdoor_4c_config
 
 
 def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, cascade_thr=None, device="cuda", model="4c", conv_dtype=None,
-                     attn_layout="quads"):
+                     attn_layout="quads", proj_gemm="split"):
     """attn_layout: the attention blocks' route (modules/quadtree_block.py::_quad_route); the timing opts into the quad-major kernels
     of the hot path, the modules' own default is token-major"""
     if model == "indoor":
-        return _time_indoor(batch, steps, warmup, conv_dtype, device, attn_layout)
+        return _time_indoor(batch, steps, warmup, conv_dtype, device, attn_layout, proj_gemm)
     cfg = outdoor_2c_config() if model == "2c" else outdoor_4c_config()
     if coarse_thr is not None:
         cfg["match_coarse"]["thr"] = coarse_thr
@@ -21,7 +21,7 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
         if "match_cascade_2c" in cfg:
             cfg["match_cascade_2c"].update(test_thr=cascade_thr, pre_thr=[0.0, 0.0])
     torch.manual_seed(0)
-    m = set_caller_layout(CasMTR4c(cfg, conv_dtype=conv_dtype).eval().to(device), attn_layout)
+    m = set_caller_layout(CasMTR4c(cfg, conv_dtype=conv_dtype).eval().to(device), attn_layout, proj_gemm)
     g = torch.Generator(device=device).manual_seed(1)
     mk = lambda: torch.rand((batch, 3, size, size), device=device, generator=g)
     sets = [(mk(), mk()) for _ in range(2)]
@@ -72,17 +72,18 @@ def time_whole_model(batch=8, size=832, steps=5, warmup=2, coarse_thr=None, casc
     _mod._CONV_DTYPE[0] = None
     out["conv_dtype"] = "fp32" if conv_dtype is None else str(conv_dtype).replace("torch.", "")
     out["attention_layout"] = attn_layout
+    out["attention_projection_gemm"] = proj_gemm
     del m, sets
     torch.cuda.empty_cache()
     return out
 
 
-def _time_indoor(batch, steps, warmup, conv_dtype, device, attn_layout="quads"):
+def _time_indoor(batch, steps, warmup, conv_dtype, device, attn_layout="quads", proj_gemm="split"):
     """CasMTRIndoor4c on 640x480 frames (BASELINE configs[4] shapes)"""
     from . import casmtr4c as _mod
     from .indoor import CasMTRIndoor4c
     torch.manual_seed(0)
-    m = set_caller_layout(CasMTRIndoor4c(conv_dtype=conv_dtype).eval().to(device), attn_layout)
+    m = set_caller_layout(CasMTRIndoor4c(conv_dtype=conv_dtype).eval().to(device), attn_layout, proj_gemm)
     g = torch.Generator(device=device).manual_seed(1)
     mk = lambda: torch.rand((batch, 3, 480, 640), device=device, generator=g)
     sets = [(mk(), mk()) for _ in range(2)]
@@ -125,7 +126,7 @@ def _time_indoor(batch, steps, warmup, conv_dtype, device, attn_layout="quads"):
            "value": round(batch / ms * 1e3, 2), "unit": "pairs/s", "ms_per_step": round(ms, 2), "batch": batch, "size": "640x480",
            "steps": steps, "stage_ms": {k: round(v / steps, 2) for k, v in acc.items()}, "matches_per_pair": round(nm / steps / batch, 1),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "data": "synthetic", "weights": "random-init",
-           "conv_dtype": "fp32" if conv_dtype is None else str(conv_dtype).replace("torch.", ""), "attention_layout": attn_layout}
+           "conv_dtype": "fp32" if conv_dtype is None else str(conv_dtype).replace("torch.", ""), "attention_layout": attn_layout, "attention_projection_gemm": proj_gemm}
     del m, sets
     torch.cuda.empty_cache()
     return out

@@ -42,13 +42,14 @@ def _project_qkv(mod, x, target):
     """q_proj(x), k_proj(target), v_proj(target) on tokens, one launch."""
     ws = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
     bs = [mod.q_proj.bias, mod.k_proj.bias, mod.v_proj.bias]
+    g = mod.proj_gemm
     if x.shape == target.shape:
         return ops.linear_multi([x, target, target], [w.detach().float() for w in ws],
-                                [None if b is None else b.detach().float() for b in bs])
+                                [None if b is None else b.detach().float() for b in bs], gemm=g)
     # different token counts (H,W != H1,W1): the query projection is its own problem shape
-    q = ops.linear(x, ws[0].detach().float(), None if bs[0] is None else bs[0].detach().float())
+    q = ops.linear(x, ws[0].detach().float(), None if bs[0] is None else bs[0].detach().float(), gemm=g)
     k, v = ops.linear_multi([target, target], [w.detach().float() for w in ws[1:]],
-                            [None if b is None else b.detach().float() for b in bs[1:]])
+                            [None if b is None else b.detach().float() for b in bs[1:]], gemm=g)
     return q, k, v
 
 
@@ -58,10 +59,11 @@ def _project_qkv_quads(mod, x, target, hw, hw1):
     bs = [mod.q_proj.bias, mod.k_proj.bias, mod.v_proj.bias]
     ws = [w.detach().float() for w in ws]
     bs = [None if b is None else b.detach().float() for b in bs]
+    g = mod.proj_gemm
     if x.shape == target.shape and tuple(hw) == tuple(hw1):
-        return ops.linear_quads_multi([x, target, target], ws, bs, *hw)
-    (q,) = ops.linear_quads_multi([x], ws[:1], bs[:1], *hw)
-    k, v = ops.linear_quads_multi([target, target], ws[1:], bs[1:], *hw1)
+        return ops.linear_quads_multi([x, target, target], ws, bs, *hw, gemm=g)
+    (q,) = ops.linear_quads_multi([x], ws[:1], bs[:1], *hw, gemm=g)
+    k, v = ops.linear_quads_multi([target, target], ws[1:], bs[1:], *hw1, gemm=g)
     return q, k, v
 
 
@@ -77,14 +79,19 @@ def _quad_route(mod):
     return (mod.layout or os.environ.get("CASMTR_CALLER_LAYOUT", "tokens")) == "quads"
 
 
-def set_caller_layout(module, layout):
+def set_caller_layout(module, layout, proj_gemm="keep"):
     """layout 'tokens' | 'quads' | None (= the CASMTR_CALLER_LAYOUT default) for every QuadtreeAttention / CascadeQuadtreeAttention
-    inside `module`; returns the module"""
+    inside `module`; proj_gemm 'exact' | 'split' | None (= ops.linear_gemm_mode's default) additionally selects how their four
+    projections multiply ('keep': unchanged).  Returns the module."""
     if layout not in ("tokens", "quads", None):
         raise ValueError(f"caller layout {layout!r} (tokens | quads | None)")
+    if proj_gemm not in ("exact", "split", None, "keep"):
+        raise ValueError(f"projection gemm {proj_gemm!r} (exact | split | None)")
     for m in module.modules():
         if isinstance(m, (QuadtreeAttention, CascadeQuadtreeAttention)):
             m.layout = layout
+            if proj_gemm != "keep":
+                m.proj_gemm = proj_gemm
     return module
 
 
@@ -110,6 +117,7 @@ class QuadtreeAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.scale = scale
         self.layout = None   # see _quad_route
+        self.proj_gemm = None   # "exact" | "split" | None (= ops.linear_gemm_mode default): see set_caller_layout
         self.apply(_init_weights)
 
     def _fused_ok(self, x, target, rel_pos):
@@ -140,7 +148,7 @@ class QuadtreeAttention(nn.Module):
                     (q,), (k, v) = ops.quad_pool_multi([q], *hw_q[i], to_tokens=last), ops.quad_pool_multi([k, v], *hw_k[i], to_tokens=last)
             msg = self.py_att.forward_quads((q, k, v), finer, hw_q, hw_k).view(B, -1, C)
             out = ops.linear(msg, self.proj.weight.detach().float(),
-                             None if self.proj.bias is None else self.proj.bias.detach().float())
+                             None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
             return self.proj_drop(out)
         q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
         queries, keys, values, hw_q, hw_k = [], [], [], [], []
@@ -156,7 +164,7 @@ class QuadtreeAttention(nn.Module):
                 h, w, h1, w1 = h // 2, w // 2, h1 // 2, w1 // 2
         msg = self.py_att.forward_tokens(queries, keys, values, hw_q, hw_k).view(B, -1, C)
         out = ops.linear(msg, self.proj.weight.detach().float(),
-                         None if self.proj.bias is None else self.proj.bias.detach().float())
+                         None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
         return self.proj_drop(out)
 
     def _forward_reference_structure(self, x, target, H, W, H1, W1, rel_pos, topk_pos):
@@ -193,6 +201,7 @@ class CascadeQuadtreeAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.scale = scale
         self.layout = None   # see _quad_route
+        self.proj_gemm = None   # "exact" | "split" | None (= ops.linear_gemm_mode default): see set_caller_layout
         self.apply(_init_weights)
 
     def forward(self, x, target, H, W, H1=None, W1=None, idx=None, rel_pos=None, want_idx=True):
@@ -209,12 +218,12 @@ class CascadeQuadtreeAttention(nn.Module):
                 q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
                 msg = self.cross_attn.forward_quads(q, k, v, (H, W), (H1, W1), idx, rel_pos)
                 out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
-                                 None if self.proj.bias is None else self.proj.bias.detach().float())
+                                 None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
                 return self.proj_drop(out), None
             q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
             msg, upsampled_idx = self.cross_attn.forward_tokens(q, k, v, (H, W), (H1, W1), idx, rel_pos, want_idx)
             out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
-                             None if self.proj.bias is None else self.proj.bias.detach().float())
+                             None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
             return self.proj_drop(out), upsampled_idx
         x = x.permute(0, 2, 1).reshape(B, C, H, W).contiguous()
         target = target.permute(0, 2, 1).reshape(B, C, H1, W1).contiguous()

@@ -162,9 +162,63 @@ def nchw_to_tokens_multi(xs):
     return outs
 
 
-def linear_multi(xs, ws, biases=None):
-    """y_i = x_i @ w_i^T (+ b_i) for up to 4 problems of one shape in one launch (k-ascending fp32 MFMA chain).
-    x_i [..., K] token-major, w_i [N, K] (a [N,K,1,1] conv weight is viewed), b_i [N] or None."""
+_LINEAR_GEMM = [None]   # process-wide default of linear_multi / linear_quads_multi (None: CASMTR_LINEAR_GEMM or "exact")
+
+
+def linear_gemm_mode(requested=None):
+    """How the projections multiply.  "exact" (default): casmtr_linear[_quads]_fwd, the fp32 MFMA fmaf chain (v_mfma_f32_32x32x2_f32,
+    k ascending) -- the oracle's arithmetic.  "split": casmtr_linear_split_fwd, fp32-accurate on the f16 matrix pipe (two-term f16
+    split of the power-of-two-normalised operands, 3 MFMA products, fp32 accumulate; |y - y_exact| <= 2^-15 |x_m||w_n|, measured ~1e-7).
+    The throughput paths opt in (pipeline.HotPath(callers), model.timing); CASMTR_LINEAR_GEMM overrides both."""
+    import os
+    mode = os.environ.get("CASMTR_LINEAR_GEMM") or requested or _LINEAR_GEMM[0] or "exact"
+    if mode not in ("exact", "split"):
+        raise ValueError(f"linear gemm mode {mode!r} (exact | split)")
+    return mode
+
+
+_WPREP = {}   # (data_ptr, version, N, K, device) -> prepared weight (f16 split tile image + factors); weights are static at inference
+
+
+def _split_weight(w):
+    import ctypes as C
+    N, K = w.shape
+    key = (w.data_ptr(), w._version, N, K, str(w.device))
+    hit = _WPREP.get(key)
+    if hit is not None:
+        return hit
+    l = _lib.lib()
+    nbytes = l.casmtr_linear_split_prep_bytes(N, K)
+    if nbytes == 0:
+        return None
+    prep = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    with torch.cuda.device(w.device):
+        _lib.check(l.casmtr_linear_split_prep(_ptr(w), _ptr(prep), N, K, _stream()), "linear_split_prep")
+    if len(_WPREP) >= 512:
+        _WPREP.clear()
+    _WPREP[key] = prep
+    return prep
+
+
+def _linear_split(xs, ws, bs, ys, M, N, K, h, w):
+    """-> False when the split path does not cover the shape (caller runs the exact kernel)"""
+    import ctypes as C
+    if N % 128 or K % 32 or K > 256:
+        return False
+    preps = [_split_weight(wt) for wt in ws]
+    if any(p is None for p in preps):
+        return False
+    n = len(xs)
+    arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    with torch.cuda.device(xs[0].device):
+        _lib.check(_lib.lib().casmtr_linear_split_fwd(arr(xs), arr(preps), arr(bs), arr(ys), n, M, N, K, h, w, _stream()),
+                   "linear_split_fwd")
+    return True
+
+
+def linear_multi(xs, ws, biases=None, gemm=None):
+    """y_i = x_i @ w_i^T (+ b_i) for up to 4 problems of one shape in one launch (k-ascending fp32 MFMA chain; gemm="split": see
+    linear_gemm_mode).  x_i [..., K] token-major, w_i [N, K] (a [N,K,1,1] conv weight is viewed), b_i [N] or None."""
     import ctypes as C
     n = len(xs)
     biases = [None] * n if biases is None else list(biases)
@@ -176,22 +230,19 @@ def linear_multi(xs, ws, biases=None):
     if any(x.shape[-1] != K or x.numel() != M * K for x in xs) or any(tuple(w.shape) != (N, K) for w in ws):
         raise RuntimeError("linear_multi: all problems must share (M, N, K)")
     ys = [torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32) for x in xs]
+    if linear_gemm_mode(gemm) == "split" and _linear_split(xs, ws, bs, ys, M, N, K, 0, 0):
+        return ys
     arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
     with torch.cuda.device(xs[0].device):
         _lib.check(_lib.lib().casmtr_linear_fwd(arr(xs), arr(ws), arr(bs), arr(ys), n, M, N, K, _stream()), "linear_fwd")
     return ys
 
 
-def linear(x, w, bias=None):
-    return linear_multi([x], [w], [bias])[0]
+def linear(x, w, bias=None, gemm=None):
+    return linear_multi([x], [w], [bias], gemm=gemm)[0]
 
 
-def linear_gemm_mode():
-    """how casmtr_linear[_quads]_fwd multiplies: 'exact' = the fp32 MFMA fmaf chain (v_mfma_f32_32x32x2_f32, k ascending)"""
-    return "exact"
-
-
-def linear_quads_multi(xs, ws, biases, h, w):
+def linear_quads_multi(xs, ws, biases, h, w, gemm=None):
     """linear_multi with the results written quad-major per head: x_i [B, h*w, K] -> [B, N/32, (h/2)*(w/2), 4, 32] (the layout
     tokens_to_quads produces), one launch, no layout pass.  h, w even, N % 32 == 0."""
     import ctypes as C
@@ -206,6 +257,8 @@ def linear_quads_multi(xs, ws, biases, h, w):
     if any(tuple(x.shape) != (B, h * w, K) for x in xs) or any(tuple(wt.shape) != (N, K) for wt in ws):
         raise RuntimeError("linear_quads_multi: x_i must be [B, h*w, K] and all problems share (N, K)")
     ys = [torch.empty((B, N // 32, (h // 2) * (w // 2), 4, 32), device=x.device, dtype=torch.float32) for x in xs]
+    if linear_gemm_mode(gemm) == "split" and h % 2 == 0 and w % 2 == 0 and _linear_split(xs, ws, bs, ys, M, N, K, h, w):
+        return ys
     arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
     with torch.cuda.device(xs[0].device):
         _lib.check(_lib.lib().casmtr_linear_quads_fwd(arr(xs), arr(ws), arr(bs), arr(ys), n, M, N, K, h, w, _stream()), "linear_quads_fwd")

@@ -61,6 +61,8 @@ class HotPathConfig:
                                       # ([B,N,C] tokens in; q/k/v + output projections and the pyramid inside the step)
     caller_layout: str = "quads"      # callers only: the blocks' route (modules/quadtree_block.py::_quad_route); the throughput path opts into
                                       # the quad-major kernels, the nn.Module default stays token-major
+    caller_gemm: str = "split"        # callers only: the blocks' projections on the f16 matrix pipe, fp32-accurate (ops.linear_gemm_mode); "exact" =
+                                      # the fp32 MFMA chain
     masked: bool = False              # MegaDepth-style padding masks (BASELINE configs[2]): bottom / right up to 20 % padded
     fresh_inputs: bool = True         # every attention layer reads its own q/k/v tensors (False: one shared set, as round 1)
     paired_layers: object = "coarse"  # False | True | "coarse".  The two directions of a layer are independent in the reference
@@ -212,7 +214,7 @@ class HotPath(torch.nn.Module):
             self.cascade_blocks = torch.nn.ModuleList(
                 torch.nn.ModuleList(unit_gain(CascadeQuadtreeAttention(st.dim, st.heads)) for _ in range(st.cross_layers))
                 for st in cfg.stages)
-            set_caller_layout(self, cfg.caller_layout)
+            set_caller_layout(self, cfg.caller_layout, cfg.caller_gemm)
         self.coarse_matching = CoarseMatching(
             {"thr": cfg.coarse_thr, "border_rm": cfg.coarse_border_rm, "train_coarse_percent": 0.3,
              "train_pad_num_gt_min": 200, "match_type": "dual_softmax", "dsmax_temperature": cfg.coarse_temperature},

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 6
+#define CASMTR_ABI_VERSION 7
 int casmtr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -232,6 +232,20 @@ int casmtr_linear_fwd(const float* const* x, const float* const* w, const float*
 int casmtr_linear_quads_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y,
                             int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream);
 
+/* The same projections, fp32-accurate, on the f16 matrix pipe (round 6; opt-in -- the default above is the exact chain).  Every operand
+ * row is scaled by a power of two and split into two f16 terms (a = hi + lo + r, |r| <= 2^-22 |a|); three v_mfma_f32_32x32x16_f16
+ * products with fp32 accumulation give x.w to |y_split - y_chain| <= 2^-15 |x_m| |w_n| (csrc/callers.hip; measured ~1e-7 |x||w|).  The
+ * reference's own conv / linear (src/model/modules/quadtree_attention.py:31-33,44,79-81,98) is a BLAS call with unspecified
+ * accumulation order, so this path's contract is that tolerance.
+ *   casmtr_linear_split_prep: weight w [N,K] -> `prep` (casmtr_linear_split_prep_bytes(N, K) bytes: the GEMM's f16 tile image + per-row
+ *     factors); once per weight tensor.  N % 128 == 0, K % 32 == 0, K <= 256, else CASMTR_ERR_UNSUPPORTED (bytes: 0).
+ *   casmtr_linear_split_fwd: y_p = x_p . w_p^T (+ bias_p) from prepared weights; h, w_ != 0: y_p quad-major as casmtr_linear_quads_fwd,
+ *     0: token-major [M,N].                                                                                                          */
+size_t casmtr_linear_split_prep_bytes(int N, int K);
+int casmtr_linear_split_prep(const float* w, void* prep, int N, int K, casmtr_stream_t stream);
+int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
+                            int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream);
+
 /* F.avg_pool2d(kernel_size=2, stride=2) of the pyramid loop (quadtree_attention.py:82-90) on QUAD-major tensors: src_i
  * [B][C/32][(h/2)*(w/2)][4][32] (h x w tokens) -> the pooled (h/2 x w/2) level, quad-major again ([B][C/32][(h/4)*(w/4)][4][32];
  * h % 4 == w % 4 == 0) or, with to_tokens, token-major [B][(h/2)*(w/2)][C] (the coarsest level's layout).  A pooled token's window
@@ -295,7 +309,7 @@ enum {
     CASMTR_PROF_COARSE_LOGITS, CASMTR_PROF_COARSE_ROW, CASMTR_PROF_COARSE_AV, CASMTR_PROF_QTA_FINE,
     CASMTR_PROF_CASCADE_ATTN, CASMTR_PROF_WINDOW_MATCH, CASMTR_PROF_NMS_SELECT, CASMTR_PROF_LAYOUT,
     CASMTR_PROF_WINDOW_WARP, CASMTR_PROF_LINEAR, CASMTR_PROF_TOKEN_POOL, CASMTR_PROF_COARSE_FUSED,
-    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_DS_SPLIT, CASMTR_PROF_DS_FIX, CASMTR_PROF_DS_GEMM_EDGE, CASMTR_PROF_LINEAR_PREP, CASMTR_PROF_COUNT
+    CASMTR_PROF_GLUE, CASMTR_PROF_QTA_FINE2, CASMTR_PROF_DS_SPLIT, CASMTR_PROF_DS_FIX, CASMTR_PROF_DS_GEMM_EDGE, CASMTR_PROF_COUNT
 };
 void casmtr_prof_enable(int on);
 /* timing experiments only: phase-elimination switches of the LDS-DMA kernels (1: no row transfers, 2: no arithmetic).

@@ -228,3 +228,106 @@ def test_block_routes_agree(monkeypatch):
     for a, b, what in zip(outs["tokens"], outs["quads"], names):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(a.abs().max())), what
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the projections on the f16 matrix pipe (ops.linear_multi(gemm="split"), csrc/callers.hip linear16_kernel)
+def _rows(kind, g, M, K):
+    x = torch.randn((M, K), generator=g)
+    if kind == "scaled":      # rows spanning 12 orders of magnitude, a few huge / tiny channels inside a row
+        x = x * torch.exp(torch.empty((M, 1)).uniform_(-14, 14, generator=g))
+        x[:, 3] *= 300.0
+        x[:, 7] *= 1e-4
+    elif kind == "sparse":    # most channels exactly zero, some rows all zero
+        x = x * (torch.rand((M, K), generator=g) < 0.1)
+        x[::17] = 0.0
+    return x.contiguous()
+
+
+@pytest.mark.parametrize("kind", ["randn", "scaled", "sparse"])
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (5408 + 37, 256, 256), (300, 256, 128), (128, 128, 256)])
+def test_linear_split_error_bound(kind, M, N, K):
+    """|y_split - y_exact_chain| <= 2^-15 |x_m| |w_n| for every output (the budget derived in csrc/callers.hip), measured with a factor to
+    spare; against float64 the split is as close as the fp32 chain itself.  Ragged M (rows beyond the last full 128-row tile), with bias."""
+    from casmtr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x, w = _rows(kind, g, M, K), _rows("randn" if kind == "sparse" else kind, g, N, K) * 0.05
+    b = torch.randn((N,), generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ye = ops.linear_multi([xd], [wd], [bd], gemm="exact")[0]
+    ys = ops.linear_multi([xd], [wd], [bd], gemm="split")[0]
+    assert ys.shape == ye.shape == (M, N)
+    scale = (x.double().norm(dim=1)[:, None] * w.double().norm(dim=1)[None, :]).to(DEV)       # |x_m| |w_n|
+    err = (ys.double() - ye.double()).abs()
+    # (+ an ulp of the result: where |bias| dwarfs |x||w| the two paths may round v + bias differently)
+    ratio = float(((err - 2.0 ** -23 * ye.double().abs()).clamp(min=0) / (2.0 ** -15 * scale + 1e-300)).max())
+    assert ratio <= 0.25, f"split vs exact chain: {ratio:.3f} of the 2^-15 |x||w| budget"
+    ref = x.double().to(DEV) @ w.double().to(DEV).T + b.double().to(DEV)
+    e_split, e_exact = (ys.double() - ref).abs(), (ye.double() - ref).abs()
+    bound = 2.0 ** -15 * scale + 2.0 ** -22 * ref.abs()
+    assert bool((e_split <= bound).all()) and bool((e_exact <= bound).all())
+    assert float(e_split.sum()) <= 2.0 * float(e_exact.sum()) + 1e-30, "on average the split is as accurate as the fp32 chain"
+
+
+def test_linear_split_multi_and_quads():
+    """three problems in one launch with k and v projecting the same tokens (one exponent pass for both); the quad-major store of the
+    split kernel is the token-major result re-laid (bit-equal); no bias / bias mixed"""
+    from casmtr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B, h, w, C = 2, 20, 28, 256
+    x, t = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
+    ws = [(0.06 * torch.randn((C, C), generator=g)).to(DEV) for _ in range(3)]
+    bs = [torch.randn((C,), generator=g).to(DEV), None, torch.randn((C,), generator=g).to(DEV)]
+    tok = ops.linear_multi([x, t, t], ws, bs, gemm="split")
+    one = [ops.linear(a, wt, bb, gemm="split") for a, wt, bb in zip((x, t, t), ws, bs)]
+    for a, b_ in zip(tok, one):
+        assert torch.equal(a, b_), "a problem's result does not depend on what shares its launch"
+    qm = ops.linear_quads_multi([x, t, t], ws, bs, h, w, gemm="split")
+    for a, b_ in zip(qm, tok):
+        assert torch.equal(a, ops.tokens_to_quads(b_, h, w))
+    ex = ops.linear_multi([x, t, t], ws, bs, gemm="exact")
+    for a, b_ in zip(tok, ex):
+        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max())
+    # shapes the split kernel does not cover run the exact kernel (same call, no error): N not a multiple of 128
+    w96 = (0.06 * torch.randn((96, C), generator=g)).to(DEV)
+    assert torch.equal(ops.linear(x, w96, None, gemm="split"), ops.linear(x, w96, None, gemm="exact"))
+    # a weight updated in place is re-prepared (cache key: data pointer + tensor version)
+    w0 = ws[0].clone()
+    y0 = ops.linear(x, w0, None, gemm="split")
+    w0.mul_(2.0)
+    assert torch.equal(ops.linear(x, w0, None, gemm="split"), 2.0 * y0)
+
+
+def test_blocks_with_split_projections(monkeypatch):
+    """QuadtreeAttention / CascadeQuadtreeAttention with proj_gemm='split' (what pipeline.HotPath(callers) and model.timing opt into)
+    against the exact-chain projections on both routes; the split kernels ran (spy)"""
+    from casmtr_amd import _lib, ops
+    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention, QuadtreeAttention, set_caller_layout
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, h, w, C, H = 2, 52, 52, 256, 8
+    x, tgt = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
+    m = QuadtreeAttention(C, H, [32, 16, 8], qkv_bias=True, scale=3).to(DEV).eval()
+    c = CascadeQuadtreeAttention(128, 4, qkv_bias=True).to(DEV).eval()
+    with torch.no_grad():   # unit-gain projections: softmaxes as sharp as a trained model's
+        for blk in (m, c):
+            for lin in (blk.q_proj, blk.k_proj, blk.v_proj, blk.proj):
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) / lin.weight.shape[1] ** 0.5)
+    hq = 26
+    xc, tc = torch.randn((B, 4 * hq * hq, 128), generator=g).to(DEV), torch.randn((B, 4 * hq * hq, 128), generator=g).to(DEV)
+    tp = ops.window_warp_idx(torch.randint(0, hq * hq, (B, hq * hq), generator=g).to(DEV), hq, hq, 5)
+    for route in ("tokens", "quads"):
+        outs = {}
+        for gm in ("exact", "split"):
+            set_caller_layout(m, route, gm), set_caller_layout(c, route, gm)
+            _lib.prof_enable(True)
+            with torch.no_grad():
+                outs[gm] = (m(x, tgt, h, w), c(xc, tc, 2 * hq, 2 * hq, idx=tp, want_idx=False)[0])
+            torch.cuda.synchronize()
+            syms = _lib.prof_symbols()
+            _lib.prof_read()
+            _lib.prof_enable(False)
+            assert ("linear16_kernel" in (syms.get("linear_nt") or "")) == (gm == "split"), (route, gm, syms.get("linear_nt"))
+        for a, b_, what in zip(outs["exact"], outs["split"], ("QuadtreeAttention", "CascadeQuadtreeAttention")):
+            # the projections differ by ~1e-7 relative; a top-k near-tie decided the other way moves single tokens further
+            d = (a - b_).abs()
+            assert float((d <= 2e-4 * float(a.abs().max())).float().mean()) >= 0.999, (route, what, float(d.max()))
