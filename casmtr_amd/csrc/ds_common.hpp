@@ -39,7 +39,8 @@ struct DsWs {  // carve of stats_ws
     float *fa, *fb;                  // [B][Lp], [B][Sp] epilogue factors (2^e / (C T), 2^e)
     int *exA, *exB;                  // [B][Lp], [B][Sp] normalisation exponents e
     float *rthr, *cthr;              // [B*L], [B*S] candidate thresholds
-    float* cg_m;                     // [B][NIB][8][S] column maxima of the 16-row groups (wr, ti, hi) of each 128-row block
+    int *fl_rn, *fl_cn, *fl_tn;      // flagged-segment lists (ds_flagged_launch): lines per (pair, column block) / (pair, row block); work items
+    int *fl_r, *fl_c, *fl_t;         // [B][NJB][L] flagged rows, [B][NIB][S] flagged columns, [B (NJB NIB' ...)] work items
     int *rcand, *ccand;              // [B*L][CAP], [B*S][CAP]
     int* xent;                       // [DS_X_CAP][2] (global row b*L+i, column j)
     float* xcf;                      // [DS_X_CAP] exact confidence of the entry
@@ -71,6 +72,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
         CARVE(namax, unsigned, B); CARVE(nbmax, unsigned, B); CARVE(ovf, int, 1);
         CARVE(xcnt, int, 4); CARVE(xln, int, 2 * (size_t)B); CARVE(rneed, unsigned char, (size_t)B * L); CARVE(cneed, unsigned char, (size_t)B * S);
         CARVE(rdec, unsigned char, (size_t)B * L);
+        CARVE(fl_rn, int, (size_t)B * NJB); CARVE(fl_cn, int, (size_t)B * NIB); CARVE(fl_tn, int, 4);
     }
     if (w) w->zero_end = base + off;
     CARVE(flags, unsigned char, (size_t)B * L); CARVE(jsel, int64_t, (size_t)B * L); CARVE(csel, float, (size_t)B * L);
@@ -80,7 +82,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
         CARVE(fa, float, (size_t)B * Lp); CARVE(fb, float, (size_t)B * Sp);
         CARVE(exA, int, (size_t)B * Lp); CARVE(exB, int, (size_t)B * Sp);
         CARVE(rthr, float, (size_t)B * L); CARVE(cthr, float, (size_t)B * S);
-        CARVE(cg_m, float, (size_t)B * NIB * 8 * S);
+        CARVE(fl_r, int, (size_t)B * NJB * L); CARVE(fl_c, int, (size_t)B * NIB * S); CARVE(fl_t, int, 2 * (size_t)B * NJB * NIB + 8);
         CARVE(rcand, int, (size_t)B * L * DS_CAND_CAP); CARVE(ccand, int, (size_t)B * S * DS_CAND_CAP);
         CARVE(xent, int, 2 * DS_X_CAP); CARVE(xcf, float, DS_X_CAP); CARVE(rlist, int, (size_t)B * DS_XL_PCAP); CARVE(clist, int, (size_t)B * DS_XL_PCAP);
         CARVE(rdec_j, int, (size_t)B * L); CARVE(rdec_cf, float, (size_t)B * L);
@@ -101,7 +103,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
 // the near-tie candidates), but the column maxima of the eight 16-row groups of the block are kept (cg_m); otherwise
 // x = acc / T and the first argmax is tracked in both directions.
 // `scratch` >= 4*32*65 + 2*2*128*3 floats, free of live data (caller has synchronised the workgroup).
-template <bool RECIP, bool SPLIT>
+template <bool RECIP, bool SPLIT, bool STORE = true>   // STORE == false (split path only): the matrix is not written
 __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scratch, const float* facA, const float* facB,
                                                  const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
                                                  float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ, int L, int S,
@@ -136,7 +138,7 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
                 float x = SPLIT ? __fmul_rn(__fmul_rn(acc[ti][tj][r], fav), fbv[tj]) : div_scalar<RECIP>(acc[ti][tj][r], T, invT);
                 if (mask0 && !(m0v && m1v[tj])) x = NEG_FILL;
                 const bool ok = rowok && colok[tj];
-                if (ok) sim[((size_t)b * L + gi) * S + j0 + wc * 64 + tj * 32 + ln] = x;
+                if (STORE && ok) sim[((size_t)b * L + gi) * S + j0 + wc * 64 + tj * 32 + ln] = x;
                 acc[ti][tj][r] = ok ? x : -INFINITY;  // out-of-range entries never win a max and add exp(-inf) = 0
             }
         }
@@ -147,12 +149,9 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             if (SPLIT) {
-                // maximum of this lane's 16-row group (wr, ti, hi): lets the sparse pass 2 read 16 rows of a column, not 128
                 float g16 = acc[ti][tj][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) g16 = fmaxf(g16, acc[ti][tj][r]);
-                const int gj = j0 + wc * 64 + tj * 32 + ln;
-                if (gj < S) w.cg_m[(((size_t)b * NIB + tI) * 8 + wr * 4 + ti * 2 + hi) * S + gj] = g16;
                 m = fmaxf(m, g16);
             } else {
 #pragma unroll
@@ -245,8 +244,8 @@ __device__ __forceinline__ void ds_tile_epilogue(f32x16 (&acc)[2][2], float* scr
 // ds_split.hip
 int ds_split_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L, int S,
                     int C, float temperature, int recip, hipStream_t s);
-int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s);
-int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, float kthr, hipStream_t s);
+int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, int store, hipStream_t s);
+int ds_flagged_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float thr, float kthr, hipStream_t s);
 int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
                   int64_t* next_idx01, int64_t* next_idx10, hipStream_t s);
 int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L,

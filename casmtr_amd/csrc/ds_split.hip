@@ -145,6 +145,31 @@ __device__ __forceinline__ void glds_2k(const char* base, unsigned voff, unsigne
                  :: "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
+// one k16 stage of a wave's 64 x 64 tile: small terms first; every accumulator is touched again only after three other MFMAs.  The GEMM
+// and the flagged-segment recompute (ds_flagged_kernel) share it: same products in the same order = bit-identical logits.
+// SWAP (the transposed problem: operand "a" holds rows of B's image): the two cross products in the other order, so that an accumulator sees
+// lo_A hi_B, hi_A lo_B, hi_A hi_B again.
+template <bool SWAP = false>
+__device__ __forceinline__ void ds16_mfma12(f32x16 (&acc)[2][2], const h16x8 (&ah)[2], const h16x8 (&al)[2], const h16x8 (&bh)[2],
+                                            const h16x8 (&bl)[2]) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+            acc[ti][tj] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+            acc[ti][tj] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+}
+
 // Epilogue of an interior tile (all 128 rows and 128 columns in range), straight from the accumulator registers (32x32 MFMA
 // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Same results as ds_tile_epilogue<true, true>
 // (ds_common.hpp, which edge tiles still use) with the per-element overhead removed: one uniform tile pointer + a 32-bit lane
@@ -152,7 +177,7 @@ __device__ __forceinline__ void glds_2k(const char* base, unsigned voff, unsigne
 // SIGN of the staged factors (facA / facB negative = masked row / column) instead of byte loads, ds_read_b128 transposes.
 //   scratch: 4 x [32][68] wave-private slabs, then rowx[2][128][2], colx[2][128][2]
 #define DS16_WL 68
-template <bool MASKED, bool WST = false>
+template <bool MASKED, bool STORE>   // STORE: the similarity matrix and the 16-row-group column maxima go to memory (dense pass 2 / tests)
 __device__ __forceinline__ void ds_split_epilogue_wave(f32x16 (&acc)[2][2], float* wl, float* rowx, float* colx, const float* facA,
                                                        const float* facB, float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ,
                                                        int L, int S, int NIB, int wr, int wc) {
@@ -162,8 +187,7 @@ __device__ __forceinline__ void ds_split_epilogue_wave(f32x16 (&acc)[2][2], floa
     const int hi = lane >> 5, ln = lane & 31;
     // addresses: wave-uniform base (SGPR pair) + 32-bit byte offset (lane part + scalar row part): no 64-bit VALU arithmetic
     char* tile = const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(sim + ((size_t)b * L + tI * DS_BM + wr * 64) * S + tJ * DS_BN + wc * 64)));
-    char* grp = const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(w.cg_m + (((size_t)b * NIB + tI) * 8 + wr * 4) * S + tJ * DS_BN + wc * 64)));
-    const unsigned lane_off = (unsigned)(4 * hi * S + ln) * 4u, grp_off = (unsigned)(hi * S + ln) * 4u;
+    const unsigned lane_off = (unsigned)(4 * hi * S + ln) * 4u;
     const unsigned row_bytes = (unsigned)S * 4u;
     float fbv[2];
     bool cmask[2];
@@ -193,17 +217,13 @@ __device__ __forceinline__ void ds_split_epilogue_wave(f32x16 (&acc)[2][2], floa
                 float x = __fmul_rn(__fmul_rn(acc[ti][tj][r], __builtin_fabsf(f)), fbv[tj]);
                 if (MASKED && (__float_as_int(f) < 0 || cmask[tj])) x = NEG_FILL;
                 const char* rowbase = tile + (size_t)(ti * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;    // wave-uniform
-                if constexpr (!WST) {
+                if constexpr (STORE) {
                     if (tj == 0) asm volatile("global_store_dword %0, %1, %2" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
                     else asm volatile("global_store_dword %0, %1, %2 offset:128" :: "v"(lane_off), "v"(x), "s"(rowbase) : "memory");
                 }
                 xv[ti][tj][r] = x;
                 g16 = fmaxf(g16, x);
             }
-            // maximum of this lane's 16-row group (wr, ti, hi): the sparse pass 2 reads 16 rows of a column, not 128
-            const char* gb = grp + (size_t)(ti * 2) * row_bytes;
-            if (tj == 0) asm volatile("global_store_dword %0, %1, %2" :: "v"(grp_off), "v"(g16), "s"(gb) : "memory");
-            else asm volatile("global_store_dword %0, %1, %2 offset:128" :: "v"(grp_off), "v"(g16), "s"(gb) : "memory");
             cmax[tj] = fmaxf(cmax[tj], g16);
         }
     }
@@ -231,16 +251,6 @@ __device__ __forceinline__ void ds_split_epilogue_wave(f32x16 (&acc)[2][2], floa
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if constexpr (WST) {   // the slab's rows as 256-byte runs: 8 stores of 1 KB instead of 32 of 256 B
-            const float* sp = wl + (lane >> 4) * DS16_WL + (lane & 15) * 4;
-            const unsigned so = (unsigned)((lane >> 4) * S + (lane & 15) * 4) * 4u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f32x4 q4 = *reinterpret_cast<const f32x4*>(sp + 4 * k * DS16_WL);
-                const char* rowbase = tile + (size_t)(ti * 32 + 4 * k) * row_bytes;    // wave-uniform
-                asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(so), "v"(q4), "s"(rowbase) : "memory");
-            }
-        }
         const f32x4* rp = reinterpret_cast<const f32x4*>(wl + ln * DS16_WL + hi * 32);
         f32x4 v[8];
 #pragma unroll
@@ -281,14 +291,14 @@ __device__ __forceinline__ void ds_split_epilogue_combine(const float* rowx, con
 }
 
 //   scratch: 4 x [32][68] wave-private slabs, then rowx[2][128][2], colx[2][128][2]
-template <bool MASKED, bool WST = false>
+template <bool MASKED, bool STORE>
 __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* scratch, const float* facA, const float* facB,
                                                   float* __restrict__ sim, const DsWs& w, int b, int tI, int tJ, int L, int S,
                                                   int NJB, int NIB) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* rowx = scratch + 4 * 32 * DS16_WL;           // [2 wc][128 rows][2]
     float* colx = rowx + 2 * 128 * 2;                   // [2 wr][128 cols][2]
-    ds_split_epilogue_wave<MASKED, WST>(acc, scratch + wave * (32 * DS16_WL), rowx, colx, facA, facB, sim, w, b, tI, tJ, L, S, NIB, wave >> 1, wave & 1);
+    ds_split_epilogue_wave<MASKED, STORE>(acc, scratch + wave * (32 * DS16_WL), rowx, colx, facA, facB, sim, w, b, tI, tJ, L, S, NIB, wave >> 1, wave & 1);
     __syncthreads();
     ds_split_epilogue_combine(rowx, colx, w, b, tI, tJ, L, S, NJB, NIB, (int)threadIdx.x);
 }
@@ -297,26 +307,23 @@ __device__ __forceinline__ void ds_split_epilogue(f32x16 (&acc)[2][2], float* sc
 // double buffered: the DMA of stage ks+1 is in flight while stage ks feeds 12 MFMAs per wave.  40 KB of LDS, <= 170 VGPRs -> 3
 // workgroups per CU: other workgroups' MFMA loops run under a workgroup's epilogue (VALU / LDS / stores).
 #define DS16_STAGE 16384
-#define DS16_LDS (4 * 32 * 65 * 4 + 2 * 2 * 128 * 3 * 4 + 2 * 128 * 4)   // epilogue scratch (aliases the stages; the interior-tile
-                                                                          // layout 4*32*68 + 2*2*128*2 floats is 512 B smaller) + factors
-#define DS16_LDS3 (3 * DS16_STAGE + 2 * 128 * 4)                          // three operand stages (prefetch distance 2) + factors
-template <int NSTG>   // operand stages in LDS: 2 (prefetch distance 1, 40 KB) or 3 (distance 2, 49 KB; still 3 workgroups per CU);
-                      // 4 = three stages + the NEXT stage's fragments read into registers under the current stage's MFMAs
+#define DS16_LDS3 (3 * DS16_STAGE + 2 * 128 * 4)                          // three operand stages (prefetch distance 2) + factors; the
+                                                                          // epilogue scratch (4*32*68 + 2*2*128*2 floats) aliases the stages
+// (Round 5 also carried a two-stage ring, a four-stage form with register-prefetched fragments, a 256 x 128 block kernel with 128 x 64
+//  wave tiles and a slab-store epilogue, all bit-identical and none faster -- DESIGN.md 14.5; pruned in round 6.)
 __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
-                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB, int skipI, int skipJ, int wst) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
+                                                           float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB, int store) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 stages x (A | B) / epilogue scratch, then facA[128] | facB[128]
     char* lds = reinterpret_cast<char*>(smem);
-    constexpr bool PF = NSTG == 4;
-    float* facA = smem + ((NSTG >= 3 ? DS16_LDS3 : DS16_LDS) - 2 * 128 * 4) / 4;
+    float* facA = smem + (DS16_LDS3 - 2 * 128 * 4) / 4;
     float* facB = facA + 128;
     const int NSJ = (NJB + 7) >> 3;
     const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
     const int st = t >> 6, wi = t & 63;
     const int tI = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
     if (tI >= NIB || tJ >= NJB) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
-    if (tI < skipI && tJ < skipJ) return;   // the interior belongs to ds_gemm16w_kernel
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
@@ -347,95 +354,26 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     const int any_masked = __syncthreads_or(masked);   // (barrier: the factor loads above have completed before any DMA is outstanding)
     glds_2k(a_src, voff, lds0);
     glds_2k(b_src, voff, lds0 + 8192);
-    if (NSTG >= 3 && KS > 1) {
+    if (KS > 1) {
         glds_2k(a_src + 8192, voff, lds0 + DS16_STAGE);
         glds_2k(b_src + 8192, voff, lds0 + DS16_STAGE + 8192);
-    }
-    if (PF && KS > 2) {
-        glds_2k(a_src + 2 * 8192, voff, lds0 + 2 * DS16_STAGE);
-        glds_2k(b_src + 2 * 8192, voff, lds0 + 2 * DS16_STAGE + 8192);
     }
     const int hi = lane >> 5, ln = lane & 31;
     // fragment (ti, part): plane (kg = hi, part), row wr*64 + ti*32 + ln
     const char* fa_base = lds + (hi * 2) * 2048 + (wr * 64 + ln) * 16;
     const char* fb_base = lds + 8192 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
-    if constexpr (PF) {
-        // Stage ks is consumed from registers while stage ks + 1 is read from LDS, stage ks + 2 is landing and stage ks + 3 is issued
-        // into the buffer stage ks was read from (everyone has read it: those reads were completed before this iteration's barrier).
-        struct Frag { h16x8 ah[2], al[2], bh[2], bl[2]; };
-        auto read = [&](Frag& f, int bufi) {
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const char* pa = fa_base + bufi * DS16_STAGE + ti * 512;
-                const char* pb = fb_base + bufi * DS16_STAGE + ti * 512;
-                f.ah[ti] = *reinterpret_cast<const h16x8*>(pa);
-                f.al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
-                f.bh[ti] = *reinterpret_cast<const h16x8*>(pb);
-                f.bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
-            }
-        };
-        auto mfmas = [&](const Frag& f) {   // small terms first; every accumulator is touched again only after three other MFMAs
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ti], f.bl[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
-        };
-        int bcur = 0;   // buffer of stage ks
-        auto step = [&](int ks, const Frag& cur, Frag& nxt) {
-            const int bn = bcur == 2 ? 0 : bcur + 1;   // buffer of stage ks + 1
-            if (ks + 1 < KS) {
-                if (ks + 2 < KS) glds_wait<4>(); else glds_wait<0>();   // stage ks + 1 has landed when only stage ks + 2 is in flight
-                lds_reads_done();
-                __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave has read stage ks out of buffer bcur
-                asm volatile("" ::: "memory");
-                if (ks + 3 < KS) {
-                    glds_2k(a_src + (size_t)(ks + 3) * 8192, voff, lds0 + (unsigned)(bcur * DS16_STAGE));
-                    glds_2k(b_src + (size_t)(ks + 3) * 8192, voff, lds0 + (unsigned)(bcur * DS16_STAGE) + 8192);
-                }
-                read(nxt, bn);
-            }
-            mfmas(cur);
-            bcur = bn;
-        };
-        Frag f0, f1;
-        if (KS > 2) glds_wait<8>(); else if (KS > 1) glds_wait<4>(); else glds_wait<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read(f0, 0);
-        for (int ks = 0; ks < KS; ks += 2) {
-            step(ks, f0, f1);
-            if (ks + 1 < KS) step(ks + 1, f1, f0);
-        }
-    } else {
     int buf = 0;
     for (int ks = 0; ks < KS; ++ks) {
-        if (NSTG == 3) {
-            // stage ks has landed when only stage ks + 1 (4 instructions) is still in flight.  No __syncthreads here: its
-            // s_waitcnt vmcnt(0) would drain the stage that was just prefetched
-            if (ks + 1 < KS) glds_wait<4>(); else glds_wait<0>();
-            lds_reads_done();
-            __builtin_amdgcn_s_barrier();   // everyone's share of stage ks has landed; everyone is done reading the buffer that is refilled next
-            asm volatile("" ::: "memory");
-            if (ks + 2 < KS) {
-                const int nb = buf >= 1 ? buf - 1 : 2;   // (ks + 2) % 3
-                glds_2k(a_src + (size_t)(ks + 2) * 8192, voff, lds0 + (unsigned)(nb * DS16_STAGE));
-                glds_2k(b_src + (size_t)(ks + 2) * 8192, voff, lds0 + (unsigned)(nb * DS16_STAGE) + 8192);
-            }
-        } else {
-            glds_wait<0>();
-            __syncthreads();   // stage ks has landed for every wave; everyone is done reading the other buffer
-            if (ks + 1 < KS) {
-                glds_2k(a_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE));
-                glds_2k(b_src + (size_t)(ks + 1) * 8192, voff, lds0 + (unsigned)((buf ^ 1) * DS16_STAGE) + 8192);
-            }
+        // stage ks has landed when only stage ks + 1 (4 instructions) is still in flight.  No __syncthreads here: its
+        // s_waitcnt vmcnt(0) would drain the stage that was just prefetched
+        if (ks + 1 < KS) glds_wait<4>(); else glds_wait<0>();
+        lds_reads_done();
+        __builtin_amdgcn_s_barrier();   // everyone's share of stage ks has landed; everyone is done reading the buffer that is refilled next
+        asm volatile("" ::: "memory");
+        if (ks + 2 < KS) {
+            const int nb = buf >= 1 ? buf - 1 : 2;   // (ks + 2) % 3
+            glds_2k(a_src + (size_t)(ks + 2) * 8192, voff, lds0 + (unsigned)(nb * DS16_STAGE));
+            glds_2k(b_src + (size_t)(ks + 2) * 8192, voff, lds0 + (unsigned)(nb * DS16_STAGE) + 8192);
         }
         h16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -447,358 +385,303 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
             bh[ti] = *reinterpret_cast<const h16x8*>(pb);
             bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
         }
-        // small terms first; every accumulator is touched again only after three other MFMAs
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
-        buf = NSTG == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
-    }
+        ds16_mfma12(acc, ah, al, bh, bl);
+        buf = buf == 2 ? 0 : buf + 1;
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
     if (tI * DS_BM + DS_BM <= L && tJ * DS_BN + DS_BN <= S) {
-        if (wst) {
+        if (store) {
             if (any_masked) ds_split_epilogue<true, true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
             else ds_split_epilogue<false, true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
-        } else if (any_masked) ds_split_epilogue<true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
-        else ds_split_epilogue<false>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+        } else if (any_masked) ds_split_epilogue<true, false>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
+        else ds_split_epilogue<false, false>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
     } else {   // edge tile: the general epilogue (bounds predication, masks from memory)
         if (tid < 128) facA[tid] = __builtin_fabsf(facA[tid]);
         else facB[tid - 128] = __builtin_fabsf(facB[tid - 128]);
         __syncthreads();
-        ds_tile_epilogue<true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
+        if (store) ds_tile_epilogue<true, true, true>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
+        else ds_tile_epilogue<true, true, false>(acc, smem, facA, facB, mask0, mask1, sim, w, b, tI, tJ, L, S, 0.f, 0.f, NJB, NIB);
     }
 }
 
-
-// The same GEMM with 128 x 64 WAVE tiles: block tile 256 x 128 = two vertically adjacent 128 x 128 tiles of the image layout, wave
-// (wrr, wc) owns the 128 rows of tile 2 tI2 + wrr and 64 columns.  Per k-stage a wave reads 12 KB of operands for 24 MFMAs instead of
-// 8 KB for 12: the 64 x 64 kernel's main loop runs at the LDS's 128 B/clk, this one has a third of that to
-// spare.  Stage = 8 KB of each A tile + 8 KB of B = 24 KB, three stages (prefetch distance 2), 128 accumulator registers: two
-// workgroups per CU.  Every accumulator sees the same MFMA sequence as in ds_gemm16_kernel and the epilogue is that kernel's, run
-// per 64 x 64 part (each wave does its parts (0, wc) and (1, wc) of its tile one after the other): bit-identical results.  Only
-// blocks whose 256 rows and 128 columns are all in range; ds_gemm16_kernel does the bottom and right strips.
-#define DS16W_STAGE 24576
-#define DS16W_LDS (3 * DS16W_STAGE + (256 + 128) * 4)
-__global__ __launch_bounds__(256, 2) void ds_gemm16w_kernel(const _Float16* __restrict__ imgA, const _Float16* __restrict__ imgB,
-                                                            const float* __restrict__ fa, const float* __restrict__ fb, int have_mask,
-                                                            float* __restrict__ sim, DsWs w, int L, int S, int KS, int NJB, int NIB,
-                                                            int NIB2, int NJBf, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 3 stages x (A0 | A1 | B) / epilogue scratch, then facA[256] | facB[128]
-    char* lds = reinterpret_cast<char*>(smem);
-    float* facA = smem + 3 * DS16W_STAGE / 4;
-    float* facB = facA + 256;
-    const int NSJ = (NJBf + 7) >> 3;
-    const int t = xcd_chunk_remap(blockIdx.x, gridDim.x);
-    const int st = t >> 6, wi = t & 63;
-    const int tI2 = (st / NSJ) * 8 + (wi >> 3), tJ = (st % NSJ) * 8 + (wi & 7);
-    if (tI2 >= NIB2 || tJ >= NJBf) return;   // padding of the super-tile grid (whole workgroup exits: no barrier is skipped)
-    const int b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wrr = wave >> 1, wc = wave & 1;
-    bool masked = false;
-    {
-        const float f = fa[((size_t)b * NIB + 2 * tI2) * 128 + tid];   // the two tiles' factors are adjacent; sign = padding mask
-        masked = have_mask && __float_as_int(f) < 0;
-        facA[tid] = f;
-        if (tid < 128) {
-            const float g = fb[((size_t)b * NJB + tJ) * 128 + tid];
-            masked = masked || (have_mask && __float_as_int(g) < 0);
-            facB[tid] = g;
-        }
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const char* a0_src = uniform_ptr(reinterpret_cast<const char*>(imgA) + ((size_t)b * NIB + 2 * tI2) * (size_t)KS * 8192);
-    const char* a1_src = a0_src + (size_t)KS * 8192;
-    const char* b_src = uniform_ptr(reinterpret_cast<const char*>(imgB) + ((size_t)b * NJB + tJ) * (size_t)KS * 8192);
-    const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_byte_addr(lds) + (unsigned)(wave * 2048)));
-    const int any_masked = __syncthreads_or(masked);   // (barrier: the factor loads above have completed before any DMA is outstanding)
-    auto issue = [&](int ks, int nb) {   // 6 DMA instructions per wave
-        const unsigned d = lds0 + (unsigned)(nb * DS16W_STAGE);
-        glds_2k(a0_src + (size_t)ks * 8192, voff, d);
-        glds_2k(a1_src + (size_t)ks * 8192, voff, d + 8192);
-        glds_2k(b_src + (size_t)ks * 8192, voff, d + 16384);
-    };
-    issue(0, 0);
-    if (KS > 1) issue(1, 1);
-    const int hi = lane >> 5, ln = lane & 31;
-    // fragment (ti, part): plane (kg = hi, part), row ti*32 + ln of this wave's A tile / column wc*64 + tj*32 + ln
-    const char* fa_base = lds + wrr * 8192 + (hi * 2) * 2048 + ln * 16;
-    const char* fb_base = lds + 16384 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
-    int buf = 0;
-    for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) glds_wait<6>(); else glds_wait<0>();   // stage ks has landed when only stage ks + 1 is still in flight
-        lds_reads_done();
-        __builtin_amdgcn_s_barrier();   // everyone's share of stage ks has landed; everyone is done reading the buffer that is refilled next
-        asm volatile("" ::: "memory");
-        if (ks + 2 < KS) issue(ks + 2, buf >= 1 ? buf - 1 : 2);
-        h16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const char* pa = fa_base + buf * DS16W_STAGE + ti * 512;
-            ah[ti] = *reinterpret_cast<const h16x8*>(pa);
-            al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
-        }
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            const char* pb = fb_base + buf * DS16W_STAGE + tj * 512;
-            bh[tj] = *reinterpret_cast<const h16x8*>(pb);
-            bl[tj] = *reinterpret_cast<const h16x8*>(pb + 2048);
-        }
-        if (dbg & 2) {   // timing experiment: no MFMAs
-            acc[0][0][0] += (float)ah[0][0] + (float)al[1][1] + (float)ah[2][2] + (float)al[3][3] + (float)bh[0][0] + (float)bl[1][1];
-            buf = buf == 2 ? 0 : buf + 1;
-            continue;
-        }
-        // small terms first (the order of ds_gemm16_kernel for every accumulator)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
-    if (dbg & 1) {   // timing experiment: no epilogue
-        float x = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x += acc[i][j][r];
-        if (x == 12345.f) sim[tid] = x;
-        return;
-    }
-    float* wl = smem + wave * (32 * DS16_WL);
-    float* xch = smem + 4 * 32 * DS16_WL;            // per tile: rowx [2 wc][128][2], colx [2 wr][128][2]
-    float* rowx = xch + wrr * 1024, *colx = rowx + 512;
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-        f32x16 (&part)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * v]);
-        if (any_masked) ds_split_epilogue_wave<true>(part, wl, rowx, colx, facA + wrr * 128, facB, sim, w, b, 2 * tI2 + wrr, tJ, L, S, NIB, v, wc);
-        else ds_split_epilogue_wave<false>(part, wl, rowx, colx, facA + wrr * 128, facB, sim, w, b, 2 * tI2 + wrr, tJ, L, S, NIB, v, wc);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) ds_split_epilogue_combine(xch + sub * 1024, xch + sub * 1024 + 512, w, b, 2 * tI2 + sub, tJ, L, S, NJB, NIB, tid);
-}
-
-int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, hipStream_t s) {
+int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, int store, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const int ntiles = ((NJB + 7) / 8) * ((NIB + 7) / 8) * 64;
-    // Default: three operand stages (prefetch distance 2): 1.78 -> 1.77 ms unmasked, 1.85 -> 1.78 ms with padding masks (round 4).  The
-    // kernel is bound by LDS bandwidth in its main loop (DESIGN.md sections 11, 12), not by the DMA latency, so this is all a deeper
-    // ring buys.  A persistent variant with the epilogue software-pipelined under the next tile's k-stages (two accumulator sets, 2
-    // workgroups per CU, 256 VGPRs with spills) was built and measured at 2.35 ms: the epilogue's slab traffic lands on the same
-    // saturated LDS; it was removed again.
-    // Interior by ds_gemm16w_kernel (128 x 64 wave tiles) where at least one 256 x 128 block is whole, the bottom / right strips by
-    // ds_gemm16_kernel (CASMTR_DS_GEMM16_WIDE=0: everything by the latter; CASMTR_DS_GEMM16_STAGES=2: its two-stage form)
-    int skipI = 0, skipJ = 0;
-    const char* evs = getenv("CASMTR_DS_GEMM16_WST");
-    const int wst = evs && evs[0] == '1';
-    const char* evw = getenv("CASMTR_DS_GEMM16_WIDE");
-    const int NIB2 = L / 256, NJBf = S / DS_BN;
-    if (evw && evw[0] == '1' && NIB2 > 0 && NJBf > 0) {
-        const int nt = ((NJBf + 7) / 8) * ((NIB2 + 7) / 8) * 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DS16W_LDS);
-        CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16w_kernel, dim3(nt, B), dim3(256), DS16W_LDS, s, w.imgA, w.imgB, w.fa, w.fb, mask0 ? 1 : 0,
-                            sim, w, L, S, C / 16, NJB, NIB, NIB2, NJBf, g_debug_flags >> 12);
-        skipI = 2 * NIB2; skipJ = NJBf;
-        if (skipI >= NIB && skipJ >= NJB) { CASMTR_CHECK_LAUNCH(); return 0; }
-    }
-    const char* ev3 = getenv("CASMTR_DS_GEMM16_STAGES");
-    if (ev3 && ev3[0] == '4') {
-        const size_t lds = DS16_LDS3;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<4>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
-                            mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, skipI, skipJ, wst);
-    } else if (ev3 && ev3[0] == '2') {
-        const size_t lds = DS16_LDS;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<2>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
-                            mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, skipI, skipJ, wst);
-    } else {
-        const size_t lds = DS16_LDS3;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        CASMTR_LAUNCH_TIMED(skipI ? CASMTR_PROF_DS_GEMM_EDGE : CASMTR_PROF_DS_GEMM, ds_gemm16_kernel<3>, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
-                            mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, skipI, skipJ, wst);
-    }
+    // Three operand stages (prefetch distance 2): 1.78 -> 1.77 ms unmasked, 1.85 -> 1.78 ms with padding masks (round 4).  A persistent
+    // variant with the epilogue software-pipelined under the next tile's k-stages (two accumulator sets, 2 workgroups per CU, 256 VGPRs
+    // with spills) was built and measured at 2.35 ms and removed; so were round 5's wide-tile / four-stage / slab-store variants.
+    // store == 0 (round 6, the sparse pass 2's configuration): the epilogue keeps only the softmax partials and segment maxima -- the
+    // 4 L S B bytes of the similarity matrix (3.74 GB at 832 x 832, B = 8), of which pass 2 read 2 %, are never written; the flagged
+    // segments are recomputed from the operand images (ds_flagged_launch).
+    const size_t lds = DS16_LDS3;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    prof_symbol_args(CASMTR_PROF_DS_GEMM, "%s", store ? " (similarity matrix stored)" : " (statistics only: no matrix store)");
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16_kernel, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
+                        mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, store);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
 
-// =================================================================================================== sparse pass 2
-// The dense pass 2 (ds_conf_kernel) streams the whole matrix to find the few entries that matter: those at or above their row's /
-// column's near-tie threshold (index candidates) and those whose confidence can exceed `thr` (conf = p01 p10 > thr needs
-// p01 > thr, i.e. x > rmax + log(thr rsum) = tau).  The GEMM epilogue already left the maximum of every (row, 128-column block)
-// and (column, 128-row block) segment in rp_m / cp_m, and a segment whose maximum is below the threshold holds no such entry --
-// on matching features that is all but one or two of a row's 85 segments.  One wave per 64 rows (lane <-> row while the
-// segment maxima stream past, coalesced); every flagged (row, block) segment is then read by the whole wave (512 B).  Column
-// segments (128 rows x one column, strided) only look for index candidates: every entry with conf > thr sits in a flagged ROW
-// segment, which also feeds the column-best atomics.  Same candidate lists and best-of-row / best-of-column keys as the dense pass.
-#define DS_SP_CHUNK 8
-__global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict__ sim, DsWs w, int B, int L, int S, int NJB, int NIB,
-                                                        float thr, float kthr) {
-    const int lane = threadIdx.x & 63;
-    const int gw0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int RG = (L + 63) / 64, CG = (S + 63) / 64;
-    const int RCH = (NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK, CCH = (NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK;   // block chunks per wave
-    if (gw0 < B * RG * RCH) {
-        const int gw = gw0 / RCH, t0 = (gw0 % RCH) * DS_SP_CHUNK;
-        const int b = gw / RG, g = gw % RG, i = g * 64 + lane;
-        const bool ok = i < L;
-        const size_t ro = (size_t)b * L + (ok ? i : L - 1);
-        const float rm = w.rmax[ro], rs = w.rsum[ro], rt = w.rthr[ro];
-        const float tau = rm + __logf(thr * rs) - 1e-2f, rinv = 1.0f / rs;
-        const float keep = 1.0f - 2.0f * ds_conf_band(kthr, w.namax[b], w.nbmax[b]), cmin = 0.9f * thr;
-        const float lim = fminf(rt, tau);
-        float mv[DS_SP_CHUNK];
+// =================================================================================================== pass 2 without the matrix
+// Round 6.  Pass 2 only ever needed the few entries that matter: those at or above their row's / column's near-tie
+// threshold (index candidates) and those whose confidence can exceed `thr` (conf = p01 p10 > thr needs p01 > thr, i.e.
+// x > rmax + log(thr rsum) = tau).  Rounds 3-5 had the GEMM write the whole [B, L, S] matrix (3.74 GB per 8-pair call at 832 x 832:
+// the largest write of the step) and a segment-sparse pass read back the ~2 % of it whose (row, 128-column) / (column, 128-row)
+// segment maximum -- left behind by the GEMM epilogue in rp_m / cp_m -- says something can matter.  Now the matrix is not written at
+// all (ds_gemm16_launch(store = 0)); the flagged segments are RECOMPUTED from the operand images:
+//   ds_flagscan_kernel   thread per row / per column walks its segment maxima and appends itself to the list of every flagged
+//                        (pair, column block) / (pair, row block);
+//   ds_flagtiles_kernel  lists -> work items of <= 128 flagged lines;
+//   ds_flagged_kernel    one 128 x 128 tile per item: the listed rows gathered from the fp32 features and split in the kernel (the bits
+//                        of ds_split_kernel's image) against the block's contiguous image of B, ds_gemm16_kernel's MFMA sequence and
+//                        scaling -- the logits are
+//                        bit-identical to what the GEMM saw (the segment maxima it left are maxima of exactly these values); then
+//                        ds_sparse's per-entry logic from the accumulator registers: candidate lists, confidences of the entries
+//                        above tau, packed best-of-row / best-of-column atomics, borderline list.  Column items are the transposed
+//                        problem (listed columns gathered out of B's image against a row block of A; the two cross products issued in
+//                        swapped order so that every accumulator again sees the GEMM's sequence) and only collect index candidates:
+//                        every entry with conf > thr sits in a flagged ROW segment.
+// ~1.5 % of the GEMM's tiles at 832 x 832 (a row's maximum sits in one or two of its 85 segments).  Degenerate inputs (all segments
+// flagged: duplicated or zero rows) make the lists long, not wrong; they overflow the candidate lists and take the exact passes anyway.
+#define DS_FL_ROWS 128
+#define DS_FL_QCAP 4000   // entries of a tile that pass their line's threshold (8 bytes each, in the 32 KB of the dead operand chunk)
+#define DS_FL_CHUNK 8
+__global__ __launch_bounds__(256) void ds_flagscan_kernel(DsWs w, int B, int L, int S, int NJB, int NIB, float thr) {
+    // thread <-> (line, chunk of 8 segments): the chunk's 8 maxima are in flight together; a wave's lanes share (pair, segment), so the
+    // compiler's wave-aggregated atomic hands out the list slots
+    const int RCH = (NJB + DS_FL_CHUNK - 1) / DS_FL_CHUNK, CCH = (NIB + DS_FL_CHUNK - 1) / DS_FL_CHUNK;
+    const int RB = (L + 255) / 256, CB = (S + 255) / 256;
+    int blk = blockIdx.x;
+    if (blk < B * RCH * RB) {
+        const int b = blk / (RCH * RB), ch = (blk / RB) % RCH, i = (blk % RB) * 256 + threadIdx.x;
+        if (i >= L) return;
+        const size_t o = (size_t)b * L + i;
+        const float rm = w.rmax[o], rs = w.rsum[o], rt = w.rthr[o];
+        const float lim = fminf(rt, rm + __logf(thr * rs) - 1e-2f);
+        float mv[DS_FL_CHUNK];
 #pragma unroll
-        for (int k = 0; k < DS_SP_CHUNK; ++k)   // all loads in flight before the first use
-            mv[k] = w.rp_m[((size_t)b * NJB + min(t0 + k, NJB - 1)) * L + (ok ? i : L - 1)];
+        for (int k = 0; k < DS_FL_CHUNK; ++k) mv[k] = w.rp_m[((size_t)b * NJB + min(ch * DS_FL_CHUNK + k, NJB - 1)) * L + i];
 #pragma unroll
-        for (int k = 0; k < DS_SP_CHUNK; ++k) {
-            const int tJ = t0 + k;
-            const float m = mv[k];
-            unsigned long long bal = __ballot(ok && tJ < NJB && m >= lim && m != NEG_FILL);
-            while (bal) {
-                // up to four flagged segments per round: their 2 x 256-byte reads are all in flight before the first is looked at (a
-                // wave meets ~9 flagged segments; one dependent HBM round trip each was what the kernel's 150 us consisted of)
-                int ls[4], nl = 0;
+        for (int k = 0; k < DS_FL_CHUNK; ++k) {
+            const int J = ch * DS_FL_CHUNK + k;
+            if (J < NJB && mv[k] >= lim && mv[k] != NEG_FILL) {
+                const int slot = atomicAdd(w.fl_rn + b * NJB + J, 1);
+                w.fl_r[((size_t)b * NJB + J) * L + slot] = i;
+            }
+        }
+        return;
+    }
+    blk -= B * RCH * RB;
+    if (blk < B * CCH * CB) {
+        const int b = blk / (CCH * CB), ch = (blk / CB) % CCH, j = (blk % CB) * 256 + threadIdx.x;
+        if (j >= S) return;
+        const float ct = w.cthr[(size_t)b * S + j];
+        float mv[DS_FL_CHUNK];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (bal) { ls[q] = __ffsll((long long)bal) - 1; bal &= bal - 1; ++nl; } else ls[q] = 0;
+        for (int k = 0; k < DS_FL_CHUNK; ++k) mv[k] = w.cp_m[((size_t)b * NIB + min(ch * DS_FL_CHUNK + k, NIB - 1)) * S + j];
+#pragma unroll
+        for (int k = 0; k < DS_FL_CHUNK; ++k) {
+            const int I = ch * DS_FL_CHUNK + k;
+            if (I < NIB && mv[k] >= ct && mv[k] != NEG_FILL) {
+                const int slot = atomicAdd(w.fl_cn + b * NIB + I, 1);
+                w.fl_c[((size_t)b * NIB + I) * S + slot] = j;
+            }
+        }
+    }
+}
+
+// work items: (list id << 8 | tile within the list), row lists first then column lists (id >= B * NJB); fl_tn[0] = their number
+__global__ __launch_bounds__(256) void ds_flagtiles_kernel(DsWs w, int nrl, int ncl) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nrl + ncl) return;
+    const int n = t < nrl ? w.fl_rn[t] : w.fl_cn[t - nrl];
+    const int nt = (n + DS_FL_ROWS - 1) / DS_FL_ROWS;
+    if (!nt) return;
+    const int base = atomicAdd(w.fl_tn, nt);
+    for (int k = 0; k < nt; ++k) w.fl_t[base + k] = (t << 8) | k;
+}
+
+__global__ __launch_bounds__(256, 2) void ds_flagged_kernel(const float* __restrict__ f0, const float* __restrict__ f1, DsWs w, int B, int L, int S,
+                                                            int C, int NJB, int NIB, float thr, float kthr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // one 32-channel chunk of the gathered lines | of the block, then the per-line tables
+    char* As = reinterpret_cast<char*>(smem);      // [kg 4][hi | lo][128 lines][8 f16]: two k16 stages of ds_gemm16_kernel's layout
+    char* Bs = As + 16384;
+    float* tab = smem + 2 * 16384 / 4;             // facA[128] | facB[128] | lim | rt | tau | rm | rinv | line[128] (int)
+    float *facA = tab, *facB = tab + 128, *t_lim = tab + 256, *t_rt = tab + 384, *t_tau = tab + 512, *t_rm = tab + 640;
+    float* t_rinv = tab + 768;
+    int* line = reinterpret_cast<int*>(tab + 896);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    const int hi = lane >> 5, ln = lane & 31;
+    const int nitems = w.fl_tn[0], nrl = B * NJB;
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int e = w.fl_t[it], id = e >> 8, tile = e & 255;
+        const bool cols = id >= nrl;                                   // wave-uniform (workgroup-uniform)
+        // rows: lines = rows of A (imgA, L of them, thresholds rt / tau), block = column block blk of B;  cols: lines = columns (imgB)
+        const int lid = cols ? id - nrl : id;
+        const int NB_blk = cols ? NIB : NJB;                           // blocks per pair on the BLOCK side
+        const int b = lid / NB_blk, blk = lid - b * NB_blk;
+        const int NL = cols ? S : L;                                   // lines per pair, blocks per pair on the LINE side
+        const int NB_line = cols ? NJB : NIB;
+        const int n = (cols ? w.fl_cn : w.fl_rn)[lid] - tile * DS_FL_ROWS;
+        const int* list = (cols ? w.fl_c : w.fl_r) + (size_t)lid * NL + tile * DS_FL_ROWS;
+        const _Float16* img_blk = cols ? w.imgA : w.imgB;
+        __syncthreads();   // the previous item's tables are no longer read
+        if (tid < 128) {
+            const int li = list[tid < n ? tid : 0];                    // short tiles repeat their first line (results discarded)
+            line[tid] = li;
+            const float f = (cols ? w.fb : w.fa)[(size_t)b * NB_line * 128 + li];
+            facA[tid] = f;
+            const size_t o = (size_t)b * NL + li;
+            if (cols) t_lim[tid] = tid < n ? w.cthr[o] : INFINITY;
+            else {
+                const float rm = w.rmax[o], rs = w.rsum[o], rt = w.rthr[o], tau = rm + __logf(thr * rs) - 1e-2f;
+                t_rt[tid] = rt; t_tau[tid] = tau; t_rm[tid] = rm; t_rinv[tid] = 1.0f / rs;
+                t_lim[tid] = tid < n ? fminf(rt, tau) : INFINITY;
+            }
+        } else facB[tid - 128] = (cols ? w.fa : w.fb)[((size_t)b * NB_blk + blk) * 128 + tid - 128];
+        __syncthreads();
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // The listed lines come from the fp32 FEATURES (one contiguous C-float row each: a 32-channel chunk is one 128-byte line per row) and are
+        // normalised and split on the way into LDS exactly as ds_split_kernel made the image (same exponent, ldexpf, f16 roundings: the same
+        // bits).  Gathering them out of the tile image instead -- 64 16-byte pieces per row, each in a line shared with seven other rows --
+        // moved 8x the bytes and cost 311 us per call (profiles/r06c_kernel_stats.csv).  The block side is its contiguous image.
+        const int KS32 = C >> 5;
+        const int lrow = tid >> 1, half = tid & 1;
+        const int gl = line[lrow];
+        const int ex = (cols ? w.exB : w.exA)[(size_t)b * NB_line * 128 + gl];
+        const float* ap = (cols ? f1 : f0) + ((size_t)b * NL + gl) * C + half * 16;
+        const char* bp = reinterpret_cast<const char*>(img_blk) + ((size_t)b * NB_blk + blk) * (size_t)KS32 * 16384 + tid * 16;
+        char* const a_dst = As + (half * 2) * 4096 + lrow * 16;
+        f32x4 av[4];
+        u32x4 bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+            bv[i] = *reinterpret_cast<const u32x4*>(bp + 4096 * i);
+        }
+        const char* fa_base = As + hi * 4096 + (wr * 64 + ln) * 16;   // k16 sub-stage s: + s * 8192; tile ti: + ti * 512; lo part: + 2048
+        const char* fb_base = Bs + hi * 4096 + (wc * 64 + ln) * 16;
+        for (int ks = 0; ks < KS32; ++ks) {
+            __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+            for (int kgl = 0; kgl < 2; ++kgl) {
+                h16x8 vh, vl;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float xn = ldexpf(av[2 * kgl + (c >> 2)][c & 3], -ex);
+                    const _Float16 h = (_Float16)xn;
+                    vh[c] = h;
+                    vl[c] = (_Float16)(xn - (float)h);
                 }
-                float xs[4][2];
+                *reinterpret_cast<h16x8*>(a_dst + kgl * 4096) = vh;
+                *reinterpret_cast<h16x8*>(a_dst + kgl * 4096 + 2048) = vl;
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float* p = sim + ((size_t)b * L + g * 64 + ls[q]) * S;
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Bs + 4096 * i + tid * 16) = bv[i];
+            if (ks + 1 < KS32) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = tJ * DS_BN + lane + 64 * u;
-                        xs[q][u] = (q < nl && j < S) ? p[j] : NEG_FILL;
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = *reinterpret_cast<const f32x4*>(ap + (ks + 1) * 32 + 4 * i);
+                    bv[i] = *reinterpret_cast<const u32x4*>(bp + (size_t)(ks + 1) * 16384 + 4096 * i);
                 }
+            }
+            __syncthreads();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q >= nl) break;   // wave-uniform
-                    const int l = ls[q];
-                    const int r = g * 64 + l;
-                    const float rm_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm), l));
-                    const float rt_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rt), l));
-                    const float tau_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tau), l));
-                    const float rinv_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv), l));
-                    const size_t o = (size_t)b * L + r;
+            for (int st = 0; st < 2; ++st) {   // the two k16 stages of the chunk, in the GEMM's order
+                h16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = tJ * DS_BN + lane + 64 * u;
-                        const float x = xs[q][u];
-                        if (x == NEG_FILL) continue;   // also: column out of range / no segment in this slot
-                        if (x >= rt_l) {
-                            const int slot = atomicAdd(w.rcnt + o, 1);
-                            if (slot < DS_CAND_CAP) w.rcand[o * DS_CAND_CAP + slot] = j; else *w.ovf = 1;
-                        }
-                        if (x > tau_l) {
-                            const size_t co = (size_t)b * S + j;
-                            const float cf = (__expf(x - w.cmax[co]) * (1.0f / w.csum[co])) * (__expf(x - rm_l) * rinv_l);
-                            if (cf >= 0.f) {
-                                const unsigned long long hi = (unsigned long long)__float_as_uint(cf) << 32;
-                                const unsigned long long oldr = atomicMax(w.rbest + o, hi | (0xFFFFFFFFu - (unsigned)j));
-                                const unsigned long long oldc = atomicMax(w.cbest + co, hi | (0xFFFFFFFFu - (unsigned)r));
-                                // Borderline entries (see ds_xdecide_launch): the previous maximum `old` and this entry are within the
-                                // error band of each other -> neither ordering is certain -> both go on the list for exact
-                                // re-decision.  Every entry within the band of the FINAL maximum is caught this way: it either
-                                // meets the final maximum as `old`, or is met as `old` by the chain of later maxima that ends there.
-                                if (cf > cmin) {
-                                    const float cr = __uint_as_float((unsigned)(oldr >> 32)), cc = __uint_as_float((unsigned)(oldc >> 32));
-                                    if (fminf(cf, cr) > cmin && fminf(cf, cr) >= fmaxf(cf, cr) * keep) {
-                                        ds_x_append(w, (int)o, j);
-                                        ds_x_append(w, (int)o, (int)(0xFFFFFFFFu - (unsigned)(oldr & 0xFFFFFFFFu)));
-                                    }
-                                    if (fminf(cf, cc) > cmin && fminf(cf, cc) >= fmaxf(cf, cc) * keep) {
-                                        ds_x_append(w, (int)o, j);
-                                        ds_x_append(w, b * L + (int)(0xFFFFFFFFu - (unsigned)(oldc & 0xFFFFFFFFu)), j);
-                                    }
-                                }
-                            }
-                        }
+                for (int ti = 0; ti < 2; ++ti) {
+                    const char* pa = fa_base + st * 8192 + ti * 512;
+                    const char* pb = fb_base + st * 8192 + ti * 512;
+                    ah[ti] = *reinterpret_cast<const h16x8*>(pa);
+                    al[ti] = *reinterpret_cast<const h16x8*>(pa + 2048);
+                    bh[ti] = *reinterpret_cast<const h16x8*>(pb);
+                    bl[ti] = *reinterpret_cast<const h16x8*>(pb + 2048);
+                }
+                if (cols) ds16_mfma12<true>(acc, ah, al, bh, bl); else ds16_mfma12<false>(acc, ah, al, bh, bl);
+            }
+        }
+        // ---- the entries, from the accumulators (32x32 C/D layout: column ln, rows (r & 3) + 8 (r >> 2) + 4 hi of each block).  Almost every
+        //      entry fails the line's threshold; the few that pass are queued in LDS (over the operand chunk, which is dead now) and handled
+        //      by one thread each afterwards -- the candidate / confidence / borderline code exists once, not once per unrolled entry (the
+        //      first version inlined it 64 times: 229 VGPRs, two workgroups per CU).
+        __syncthreads();   // every wave is done with the last chunk
+        int* qn = reinterpret_cast<int*>(As);                  // [0] = queued entries
+        int2* queue = reinterpret_cast<int2*>(As + 16);        // (lr << 8 | lc, x bits)
+        if (tid == 0) qn[0] = 0;
+        __syncthreads();
+        // (opaque copy of the lane id: otherwise the 64 packed (row, column) codes and table addresses of the entries are loop-invariant
+        //  and get hoisted out of the item loop into 100+ VGPRs that stay live through the k-loop -- 345 spills at three workgroups per CU)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int hi = lane_o >> 5, ln = lane_o & 31;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int lc = wc * 64 + tj * 32 + ln;                     // position in the block
+            const float fbs = facB[lc];
+            const bool c_ok = blk * 128 + lc < (cols ? L : S) && __float_as_int(fbs) >= 0;   // in range and not padding
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                asm volatile("" ::: "memory");   // one 32 x 32 block at a time: without it all 64 table reads are hoisted (128 more live registers)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float fas = facA[lr];
+                    // the GEMM's scaling order: (acc * |factor of A's row|) * |factor of B's column|
+                    const float x = cols ? __fmul_rn(__fmul_rn(acc[ti][tj][r], __builtin_fabsf(fbs)), __builtin_fabsf(fas))
+                                         : __fmul_rn(__fmul_rn(acc[ti][tj][r], __builtin_fabsf(fas)), __builtin_fabsf(fbs));
+                    if (c_ok && x >= t_lim[lr] && __float_as_int(fas) >= 0) {
+                        const int slot = atomicAdd(qn, 1);
+                        if (slot < DS_FL_QCAP) queue[slot] = make_int2((lr << 8) | lc, __float_as_int(x));
                     }
                 }
             }
         }
-    } else if (gw0 < B * RG * RCH + B * CG * CCH) {
-        const int gc0 = gw0 - B * RG * RCH;
-        const int gc = gc0 / CCH, t0 = (gc0 % CCH) * DS_SP_CHUNK;
-        const int b = gc / CG, g = gc % CG, j = g * 64 + lane;
-        const bool ok = j < S;
-        const float ct = w.cthr[(size_t)b * S + (ok ? j : S - 1)];
-        float mv[DS_SP_CHUNK];
-#pragma unroll
-        for (int k = 0; k < DS_SP_CHUNK; ++k)
-            mv[k] = w.cp_m[((size_t)b * NIB + min(t0 + k, NIB - 1)) * S + (ok ? j : S - 1)];
-#pragma unroll
-        for (int k = 0; k < DS_SP_CHUNK; ++k) {
-            const int tI = t0 + k;
-            const float m = mv[k];
-            unsigned long long bal = __ballot(ok && tI < NIB && m >= ct && m != NEG_FILL);
-            while (bal) {   // four flagged column segments per round, their group maxima and then their entries in flight together
-                int ls[4], nl = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (bal) { ls[q] = __ffsll((long long)bal) - 1; bal &= bal - 1; ++nl; } else ls[q] = 0;
-                }
-                float gm[4][2], xs[4][2], ctl[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int col = g * 64 + ls[q];
-                    ctl[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ct), ls[q]));
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)   // row lane + 64 u of the block belongs to the 16-row group (wr = u, ti = lane >> 5, hi = (lane >> 2) & 1)
-                        gm[q][u] = q < nl ? w.cg_m[(((size_t)b * NIB + tI) * 8 + u * 4 + (lane >> 5) * 2 + ((lane >> 2) & 1)) * S + col] : NEG_FILL;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int col = g * 64 + ls[q];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int i = tI * DS_BM + lane + 64 * u;
-                        xs[q][u] = (q < nl && i < L && gm[q][u] >= ctl[q]) ? sim[((size_t)b * L + i) * S + col] : NEG_FILL;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q >= nl) break;   // wave-uniform
-                    const size_t co = (size_t)b * S + g * 64 + ls[q];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int i = tI * DS_BM + lane + 64 * u;
-                        const float x = xs[q][u];
-                        if (x == NEG_FILL || !(x >= ctl[q])) continue;
-                        const int slot = atomicAdd(w.ccnt + co, 1);
-                        if (slot < DS_CAND_CAP) w.ccand[co * DS_CAND_CAP + slot] = i; else *w.ovf = 1;
+        __syncthreads();
+        const int nq = qn[0];
+        if (nq > DS_FL_QCAP && tid == 0) *w.ovf = 1;   // a tile full of (near-)equal entries: the exact passes decide the call
+        const float keep = 1.0f - 2.0f * ds_conf_band(kthr, w.namax[b], w.nbmax[b]), cmin = 0.9f * thr;
+        for (int q = tid; q < min(nq, DS_FL_QCAP); q += 256) {
+            const int2 ent = queue[q];
+            const int lr = ent.x >> 8, lc = ent.x & 255, gc = blk * 128 + lc, li = line[lr];
+            const float x = __int_as_float(ent.y);
+            if (cols) {
+                const size_t co = (size_t)b * S + li;
+                const int slot = atomicAdd(w.ccnt + co, 1);
+                if (slot < DS_CAND_CAP) w.ccand[co * DS_CAND_CAP + slot] = gc; else *w.ovf = 1;
+                continue;
+            }
+            const size_t o = (size_t)b * L + li;
+            const int j = gc;
+            if (x >= t_rt[lr]) {
+                const int slot = atomicAdd(w.rcnt + o, 1);
+                if (slot < DS_CAND_CAP) w.rcand[o * DS_CAND_CAP + slot] = j; else *w.ovf = 1;
+            }
+            if (x > t_tau[lr]) {
+                const size_t co = (size_t)b * S + j;
+                const float cf = (__expf(x - w.cmax[co]) * (1.0f / w.csum[co])) * (__expf(x - t_rm[lr]) * t_rinv[lr]);
+                if (cf >= 0.f) {
+                    const unsigned long long hk = (unsigned long long)__float_as_uint(cf) << 32;
+                    const unsigned long long oldr = atomicMax(w.rbest + o, hk | (0xFFFFFFFFu - (unsigned)j));
+                    const unsigned long long oldc = atomicMax(w.cbest + co, hk | (0xFFFFFFFFu - (unsigned)li));
+                    // borderline entries (ds_xdecide_launch): the previous maximum and this entry within the error band of each other
+                    if (cf > cmin) {
+                        const float cr = __uint_as_float((unsigned)(oldr >> 32)), cc = __uint_as_float((unsigned)(oldc >> 32));
+                        if (fminf(cf, cr) > cmin && fminf(cf, cr) >= fmaxf(cf, cr) * keep) {
+                            ds_x_append(w, (int)o, j);
+                            ds_x_append(w, (int)o, (int)(0xFFFFFFFFu - (unsigned)(oldr & 0xFFFFFFFFu)));
+                        }
+                        if (fminf(cf, cc) > cmin && fminf(cf, cc) >= fmaxf(cf, cc) * keep) {
+                            ds_x_append(w, (int)o, j);
+                            ds_x_append(w, b * L + (int)(0xFFFFFFFFu - (unsigned)(oldc & 0xFFFFFFFFu)), j);
+                        }
                     }
                 }
             }
@@ -806,11 +689,35 @@ __global__ __launch_bounds__(256) void ds_sparse_kernel(const float* __restrict_
     }
 }
 
-int ds_sparse_launch(const float* sim, const DsWs& w, int B, int L, int S, float thr, float kthr, hipStream_t s) {
+int ds_flagged_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float thr, float kthr, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
-    const int waves = B * ((L + 63) / 64) * ((NJB + DS_SP_CHUNK - 1) / DS_SP_CHUNK) + B * ((S + 63) / 64) * ((NIB + DS_SP_CHUNK - 1) / DS_SP_CHUNK);
-    hipLaunchKernelGGL(ds_sparse_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, sim, w, B, L, S, NJB, NIB, thr, kthr);
+    const int nscan = B * ((NJB + DS_FL_CHUNK - 1) / DS_FL_CHUNK) * ((L + 255) / 256) + B * ((NIB + DS_FL_CHUNK - 1) / DS_FL_CHUNK) * ((S + 255) / 256);
+    hipLaunchKernelGGL(ds_flagscan_kernel, dim3(nscan), dim3(256), 0, s, w, B, L, S, NJB, NIB, thr);
+    hipLaunchKernelGGL(ds_flagtiles_kernel, dim3((B * (NJB + NIB) + 255) / 256), dim3(256), 0, s, w, B * NJB, B * NIB);
     CASMTR_CHECK_LAUNCH();
+    constexpr size_t lds = 2 * 16384 + 1024 * 4;
+    static int resident_tab[CASMTR_MAX_DEVICES] = {0};
+    int resident = 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_flagged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (const int r = resident_workgroups(resident_tab, ds_flagged_kernel, 256, lds, &resident)) return r;
+    hipLaunchKernelGGL(ds_flagged_kernel, dim3((unsigned)resident), dim3(256), lds, s, feat0, feat1, w, B, L, S, C, NJB, NIB, thr, kthr);
+    CASMTR_CHECK_LAUNCH();
+    if (getenv("CASMTR_DS_DEBUG")) {   // diagnostic only: synchronises
+        int nt = 0;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(&nt, w.fl_tn, sizeof nt, hipMemcpyDeviceToHost);
+        int* cn = (int*)calloc((size_t)B * (NJB + NIB), sizeof(int));
+        if (cn) {
+            (void)hipMemcpy(cn, w.fl_rn, sizeof(int) * (size_t)B * NJB, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(cn + B * NJB, w.fl_cn, sizeof(int) * (size_t)B * NIB, hipMemcpyDeviceToHost);
+            long long nr = 0, nc = 0;
+            for (int i = 0; i < B * NJB; ++i) nr += cn[i];
+            for (int i = 0; i < B * NIB; ++i) nc += cn[B * NJB + i];
+            fprintf(stderr, "ds_flagged: %lld flagged row segments of %lld (%.2f %%), %lld column segments of %lld, %d work items of <= %d lines on %d workgroups\n",
+                    nr, (long long)B * NJB * L, 100.0 * nr / ((double)B * NJB * L), nc, (long long)B * NIB * S, nt, DS_FL_ROWS, resident);
+            free(cn);
+        }
+    }
     return 0;
 }
 

@@ -514,7 +514,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     if (C > 256 || (C & 63) || L > 32768 || S > 32768)   // the exact re-decision stages a feature row of <= 256 channels in LDS and <= 256 block partials per
                    // line (every shipped config: C = 256, 10 816 tokens): wider features / larger grids take
                    // the all-fp32 path, whose workspace is a prefix of this one
-        return casmtr_dual_softmax_fwd(feat0, feat1, mask0, mask1, temperature, recip, thr, border_rm, valid_hw, h0c, w0c, h1c, w1c, want_conf,
+        return casmtr_dual_softmax_fwd(feat0, feat1, mask0, mask1, temperature, recip, thr, border_rm, valid_hw, h0c, w0c, h1c, w1c, want_conf == 1,
                                        sim_ws, stats_ws, next_idx01, next_conf01, next_idx10, next_conf10, b_ids, i_ids, j_ids, mconf, n_matches,
                                        B, L, S, C, stream);
     hipStream_t s = (hipStream_t)stream;
@@ -527,13 +527,16 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
                        (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)) / sizeof(unsigned long long), (const int*)nullptr);
     CASMTR_CHECK_LAUNCH();
     int rc;
+    const bool dense = want_conf == 1 || thr < 1e-3f;   // pass 2 streams the stored matrix (needed to write conf_matrix; log(thr rsum) undefined)
     {
         ProfScope ps(CASMTR_PROF_DS_SPLIT, s, "ds_rownorm_kernel x2 + ds_nmax_kernel + ds_split_kernel x2");
         rc = ds_split_launch(feat0, feat1, mask0, mask1, w, B, L, S, C, temperature, recip, s);
     }
     if (rc) return rc;
     {
-        rc = ds_gemm16_launch(mask0, mask1, sim_ws, w, B, L, S, C, s);   // timed inside (events attached to the dispatch)
+        // the matrix itself is only written where something reads it: conf_matrix output / the dense pass 2 (want_conf == 1, thr < 1e-3)
+        // or a caller that asked for the similarity matrix (want_conf == 2: tests)
+        rc = ds_gemm16_launch(mask0, mask1, sim_ws, w, B, L, S, C, dense || want_conf == 2, s);   // timed inside (events attached to the dispatch)
     }
     if (rc) return rc;
     const float kthr = 6.103515625e-05f / temperature;   // 2 e = 2^-14 |a_i|/sqrtC max|b_j|/sqrtC / T
@@ -547,13 +550,13 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
         CASMTR_CHECK_LAUNCH();
     }
     {
-        ProfScope ps(CASMTR_PROF_DS_CONF, s, (!want_conf && thr >= 1e-3f) ? "ds_sparse_kernel (segment-sparse pass 2)" : "ds_conf_kernel<true>");
-        if (!want_conf && thr >= 1e-3f) {   // segment-sparse pass 2 (the dense one is needed only to write conf_matrix)
-            rc = ds_sparse_launch(sim_ws, w, B, L, S, thr, kthr, s);
+        ProfScope ps(CASMTR_PROF_DS_CONF, s, !dense ? "ds_flagscan_kernel + ds_flagtiles_kernel + ds_flagged_kernel (flagged segments recomputed)" : "ds_conf_kernel<true>");
+        if (!dense) {   // pass 2 on the flagged segments only, recomputed from the operand images (no matrix in memory)
+            rc = ds_flagged_launch(feat0, feat1, w, B, L, S, C, thr, kthr, s);
             if (rc) return rc;
         } else
             hipLaunchKernelGGL(ds_conf_kernel<true>, dim3((S + 1023) / 1024, (L + DSC_ROWS - 1) / DSC_ROWS, B), dim3(256), 0, s, sim_ws,
-                               w, L, S, want_conf, thr, nullptr, kthr);
+                               w, L, S, want_conf == 1, thr, nullptr, kthr);
     }
     CASMTR_CHECK_LAUNCH();
     {
@@ -568,7 +571,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
         // a list overflowed: the exact passes below decide everything; the re-decisions made from the (truncated) lists are dropped
         hipLaunchKernelGGL(ds_zero_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(w.rdec),
                            ((size_t)B * L + 7) / 8, (const int*)w.ovf);
-        rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
+        rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf == 1, sim_ws, w, next_idx01, next_conf01,
                              next_idx10, next_conf10, B, L, S, C, w.ovf, s);
     }
     if (rc) return rc;

@@ -38,18 +38,37 @@ def _init_weights(m):
             m.bias.data.zero_()
 
 
+def _preps(mod, lins):
+    """prepared (f16-split) weights of `lins` when the block's projections run on the split path, else None.  Cached on the module per
+    layer, re-prepared when the parameter's storage or version counter changes (load_state_dict, an optimiser step, .to(device))."""
+    if ops.linear_gemm_mode(mod.proj_gemm) != "split":
+        return None
+    cache = mod.__dict__.setdefault("_split_prep", {})
+    out = []
+    for lin in lins:
+        w = lin.weight
+        tag = (w.data_ptr(), w._version, str(w.device), w.dtype)
+        hit = cache.get(id(lin))
+        if hit is None or hit[0] != tag:
+            hit = (tag, ops.prepare_split_weight(w.detach().float().reshape(w.shape[0], -1).contiguous()) if w.is_cuda else None)
+            cache[id(lin)] = hit
+        out.append(hit[1])
+    return None if any(p is None for p in out) else out
+
+
 def _project_qkv(mod, x, target):
     """q_proj(x), k_proj(target), v_proj(target) on tokens, one launch."""
     ws = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
     bs = [mod.q_proj.bias, mod.k_proj.bias, mod.v_proj.bias]
     g = mod.proj_gemm
+    pp = _preps(mod, [mod.q_proj, mod.k_proj, mod.v_proj])
     if x.shape == target.shape:
         return ops.linear_multi([x, target, target], [w.detach().float() for w in ws],
-                                [None if b is None else b.detach().float() for b in bs], gemm=g)
+                                [None if b is None else b.detach().float() for b in bs], gemm=g, preps=pp)
     # different token counts (H,W != H1,W1): the query projection is its own problem shape
-    q = ops.linear(x, ws[0].detach().float(), None if bs[0] is None else bs[0].detach().float(), gemm=g)
+    q = ops.linear(x, ws[0].detach().float(), None if bs[0] is None else bs[0].detach().float(), gemm=g, prep=pp[0] if pp else None)
     k, v = ops.linear_multi([target, target], [w.detach().float() for w in ws[1:]],
-                            [None if b is None else b.detach().float() for b in bs[1:]], gemm=g)
+                            [None if b is None else b.detach().float() for b in bs[1:]], gemm=g, preps=pp[1:] if pp else None)
     return q, k, v
 
 
@@ -60,10 +79,11 @@ def _project_qkv_quads(mod, x, target, hw, hw1):
     ws = [w.detach().float() for w in ws]
     bs = [None if b is None else b.detach().float() for b in bs]
     g = mod.proj_gemm
+    pp = _preps(mod, [mod.q_proj, mod.k_proj, mod.v_proj])
     if x.shape == target.shape and tuple(hw) == tuple(hw1):
-        return ops.linear_quads_multi([x, target, target], ws, bs, *hw, gemm=g)
-    (q,) = ops.linear_quads_multi([x], ws[:1], bs[:1], *hw, gemm=g)
-    k, v = ops.linear_quads_multi([target, target], ws[1:], bs[1:], *hw1, gemm=g)
+        return ops.linear_quads_multi([x, target, target], ws, bs, *hw, gemm=g, preps=pp)
+    (q,) = ops.linear_quads_multi([x], ws[:1], bs[:1], *hw, gemm=g, preps=pp[:1] if pp else None)
+    k, v = ops.linear_quads_multi([target, target], ws[1:], bs[1:], *hw1, gemm=g, preps=pp[1:] if pp else None)
     return q, k, v
 
 
@@ -148,7 +168,8 @@ class QuadtreeAttention(nn.Module):
                     (q,), (k, v) = ops.quad_pool_multi([q], *hw_q[i], to_tokens=last), ops.quad_pool_multi([k, v], *hw_k[i], to_tokens=last)
             msg = self.py_att.forward_quads((q, k, v), finer, hw_q, hw_k).view(B, -1, C)
             out = ops.linear(msg, self.proj.weight.detach().float(),
-                             None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
+                             None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm,
+                             prep=(_preps(self, [self.proj]) or [None])[0])
             return self.proj_drop(out)
         q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
         queries, keys, values, hw_q, hw_k = [], [], [], [], []
@@ -164,7 +185,8 @@ class QuadtreeAttention(nn.Module):
                 h, w, h1, w1 = h // 2, w // 2, h1 // 2, w1 // 2
         msg = self.py_att.forward_tokens(queries, keys, values, hw_q, hw_k).view(B, -1, C)
         out = ops.linear(msg, self.proj.weight.detach().float(),
-                         None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
+                         None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm,
+                             prep=(_preps(self, [self.proj]) or [None])[0])
         return self.proj_drop(out)
 
     def _forward_reference_structure(self, x, target, H, W, H1, W1, rel_pos, topk_pos):
@@ -218,12 +240,14 @@ class CascadeQuadtreeAttention(nn.Module):
                 q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
                 msg = self.cross_attn.forward_quads(q, k, v, (H, W), (H1, W1), idx, rel_pos)
                 out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
-                                 None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
+                                 None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm,
+                             prep=(_preps(self, [self.proj]) or [None])[0])
                 return self.proj_drop(out), None
             q, k, v = _project_qkv(self, x.contiguous().float(), target.contiguous().float())
             msg, upsampled_idx = self.cross_attn.forward_tokens(q, k, v, (H, W), (H1, W1), idx, rel_pos, want_idx)
             out = ops.linear(msg.view(B, -1, C), self.proj.weight.detach().float(),
-                             None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm)
+                             None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm,
+                             prep=(_preps(self, [self.proj]) or [None])[0])
             return self.proj_drop(out), upsampled_idx
         x = x.permute(0, 2, 1).reshape(B, C, H, W).contiguous()
         target = target.permute(0, 2, 1).reshape(B, C, H1, W1).contiguous()

@@ -177,16 +177,13 @@ def linear_gemm_mode(requested=None):
     return mode
 
 
-_WPREP = {}   # (data_ptr, version, N, K, device) -> prepared weight (f16 split tile image + factors); weights are static at inference
-
-
-def _split_weight(w):
-    import ctypes as C
+def prepare_split_weight(w):
+    """weight [N, K] (fp32, contiguous, device-resident) -> the prepared form casmtr_linear_split_fwd multiplies with (f16 split tile image
+    + per-row factors), or None when the split kernel does not cover the shape.  Depends on the weight's VALUES: callers that keep it
+    (modules/quadtree_block.py caches it per parameter, keyed by the parameter's data pointer and version counter) must re-prepare after
+    the weight changes.  ops.linear_multi(gemm="split") without `preps` prepares on every call (a [N]-block kernel, microseconds)."""
+    w = _chk(w.reshape(w.shape[0], -1), "w")
     N, K = w.shape
-    key = (w.data_ptr(), w._version, N, K, str(w.device))
-    hit = _WPREP.get(key)
-    if hit is not None:
-        return hit
     l = _lib.lib()
     nbytes = l.casmtr_linear_split_prep_bytes(N, K)
     if nbytes == 0:
@@ -194,18 +191,15 @@ def _split_weight(w):
     prep = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     with torch.cuda.device(w.device):
         _lib.check(l.casmtr_linear_split_prep(_ptr(w), _ptr(prep), N, K, _stream()), "linear_split_prep")
-    if len(_WPREP) >= 512:
-        _WPREP.clear()
-    _WPREP[key] = prep
     return prep
 
 
-def _linear_split(xs, ws, bs, ys, M, N, K, h, w):
+def _linear_split(xs, ws, bs, ys, M, N, K, h, w, preps=None):
     """-> False when the split path does not cover the shape (caller runs the exact kernel)"""
     import ctypes as C
     if N % 128 or K % 32 or K > 256:
         return False
-    preps = [_split_weight(wt) for wt in ws]
+    preps = [prepare_split_weight(wt) for wt in ws] if preps is None else list(preps)
     if any(p is None for p in preps):
         return False
     n = len(xs)
@@ -216,7 +210,7 @@ def _linear_split(xs, ws, bs, ys, M, N, K, h, w):
     return True
 
 
-def linear_multi(xs, ws, biases=None, gemm=None):
+def linear_multi(xs, ws, biases=None, gemm=None, preps=None):
     """y_i = x_i @ w_i^T (+ b_i) for up to 4 problems of one shape in one launch (k-ascending fp32 MFMA chain; gemm="split": see
     linear_gemm_mode).  x_i [..., K] token-major, w_i [N, K] (a [N,K,1,1] conv weight is viewed), b_i [N] or None."""
     import ctypes as C
@@ -230,7 +224,7 @@ def linear_multi(xs, ws, biases=None, gemm=None):
     if any(x.shape[-1] != K or x.numel() != M * K for x in xs) or any(tuple(w.shape) != (N, K) for w in ws):
         raise RuntimeError("linear_multi: all problems must share (M, N, K)")
     ys = [torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32) for x in xs]
-    if linear_gemm_mode(gemm) == "split" and _linear_split(xs, ws, bs, ys, M, N, K, 0, 0):
+    if linear_gemm_mode(gemm) == "split" and _linear_split(xs, ws, bs, ys, M, N, K, 0, 0, preps):
         return ys
     arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
     with torch.cuda.device(xs[0].device):
@@ -238,11 +232,11 @@ def linear_multi(xs, ws, biases=None, gemm=None):
     return ys
 
 
-def linear(x, w, bias=None, gemm=None):
-    return linear_multi([x], [w], [bias], gemm=gemm)[0]
+def linear(x, w, bias=None, gemm=None, prep=None):
+    return linear_multi([x], [w], [bias], gemm=gemm, preps=None if prep is None else [prep])[0]
 
 
-def linear_quads_multi(xs, ws, biases, h, w, gemm=None):
+def linear_quads_multi(xs, ws, biases, h, w, gemm=None, preps=None):
     """linear_multi with the results written quad-major per head: x_i [B, h*w, K] -> [B, N/32, (h/2)*(w/2), 4, 32] (the layout
     tokens_to_quads produces), one launch, no layout pass.  h, w even, N % 32 == 0."""
     import ctypes as C
@@ -257,7 +251,7 @@ def linear_quads_multi(xs, ws, biases, h, w, gemm=None):
     if any(tuple(x.shape) != (B, h * w, K) for x in xs) or any(tuple(wt.shape) != (N, K) for wt in ws):
         raise RuntimeError("linear_quads_multi: x_i must be [B, h*w, K] and all problems share (N, K)")
     ys = [torch.empty((B, N // 32, (h // 2) * (w // 2), 4, 32), device=x.device, dtype=torch.float32) for x in xs]
-    if linear_gemm_mode(gemm) == "split" and h % 2 == 0 and w % 2 == 0 and _linear_split(xs, ws, bs, ys, M, N, K, h, w):
+    if linear_gemm_mode(gemm) == "split" and h % 2 == 0 and w % 2 == 0 and _linear_split(xs, ws, bs, ys, M, N, K, h, w, preps):
         return ys
     arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
     with torch.cuda.device(xs[0].device):
@@ -588,8 +582,10 @@ def ds_gemm_mode(requested=None):
 
 
 def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=None, mask1=None, valid_hw=None,
-                 recip=True, want_conf=True, gemm=None):
-    """CoarseMatching numerics.  Returns a dict; match lists are capacity-sized, `n` is a device int64 scalar."""
+                 recip=True, want_conf=True, gemm=None, want_sim=False):
+    """CoarseMatching numerics.  Returns a dict; match lists are capacity-sized, `n` is a device int64 scalar.
+    want_conf: conf_matrix [B,L,S] is written.  Without it the split path (gemm='split') does not write the similarity matrix either
+    (its pass 2 recomputes the few segments that matter); want_sim=True asks for it (`sim`: tests).  The exact path always has it."""
     _chk(feat0, "feat0"), _chk(feat1, "feat1")
     mask0, mask1 = _u8(mask0), _u8(mask1)
     _chk(valid_hw, "valid_hw", torch.int32)
@@ -612,10 +608,10 @@ def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=No
     with torch.cuda.device(dev):
         _lib.check(fwd(_ptr(feat0), _ptr(feat1), _ptr(mask0), _ptr(mask1), float(temperature),
                        int(bool(recip)), float(thr), int(border_rm), _ptr(valid_hw), hw0[0], hw0[1],
-                       hw1[0], hw1[1], int(bool(want_conf)), _ptr(sim), _ptr(ws), _ptr(ni01),
+                       hw1[0], hw1[1], 1 if want_conf else (2 if want_sim else 0), _ptr(sim), _ptr(ws), _ptr(ni01),
                        _ptr(nc01), _ptr(ni10), _ptr(nc10), _ptr(bi), _ptr(ii), _ptr(ji), _ptr(mc),
                        _ptr(n), B, L, S, Cc, _stream()), "dual_softmax_fwd")
-    return dict(conf_matrix=sim if want_conf else None, sim=None if want_conf else sim, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
+    return dict(conf_matrix=sim if want_conf else None, sim=sim if (not want_conf and (want_sim or not split)) else None, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
                 next_conf_c10=nc10, b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n)
 
 
