@@ -19,11 +19,12 @@ BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_k
               ("cascade_quad_kernel", "cascade_attn"),
               ("coarse_fused_kernel", "qta_coarsest_level"), ("coarse_tile_kernel", "qta_coarsest_level"), ("window_match", "window_match"),
               ("ds_gemm16_kernel", "dual_softmax_gemm"), ("ds_gemm_kernel<", "dual_softmax_gemm[exact fp32; in split mode: the guarded fallback launch]"),
+              ("ds_flagged_kernel", "dual_softmax_pass2"), ("ds_flagscan_kernel", "dual_softmax_pass2[flag scan]"),
               ("ds_sparse_kernel", "dual_softmax_pass2"), ("ds_conf_kernel", "dual_softmax_pass2[dense]"),
               ("ds_split_kernel", "dual_softmax_split_prepass"), ("ds_rownorm_kernel", "dual_softmax_split_prepass"), ("ds_fix_kernel", "dual_softmax_fix"),
               ("nchw_to_tokens_kernel", "layout[token-major]"), ("coarse_row_kernel", "coarse_row_kernel"),
               ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel"),
-              ("linear_nt_kernel", "linear_nt"), ("token_pool_kernel", "token_pool")]
+              ("linear_nt_kernel", "linear_nt"), ("linear16_kernel", "linear_nt"), ("token_pool_kernel", "token_pool"), ("quad_pool_kernel", "token_pool")]
 
 
 def per_kernel(path, counter):
