@@ -18,6 +18,7 @@ _P, _I, _F, _SZ, _LL = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 # name -> (restype, argtypes): exactly the prototypes of include/casmtr_hip.h
 SIGNATURES = {
     "casmtr_abi_version": (_I, []),
+    "casmtr_debug_work_counters_nonzero": (_I, []),
     "casmtr_qta_score_fwd": (_I, [_P] * 4 + [_I] * 6 + [_P]),
     "casmtr_qta_score_bwd": (_I, [_P] * 6 + [_I] * 6 + [_P]),
     "casmtr_qta_value_agg_fwd": (_I, [_P] * 4 + [_I] * 6 + [_P]),

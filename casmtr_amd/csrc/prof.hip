@@ -11,9 +11,12 @@
 
 namespace casmtr {
 // ---- work counters of the persistent gather kernels (dynamic item claiming, common.hpp)
+static constexpr int WORK_NSLOT = 64;
+static int* g_work_base[CASMTR_MAX_DEVICES] = {nullptr};
+
 int* work_counters() {
-    constexpr int NSLOT = 64;
-    static int* base[CASMTR_MAX_DEVICES] = {nullptr};
+    constexpr int NSLOT = WORK_NSLOT;
+    int** base = g_work_base;
     static unsigned seq[CASMTR_MAX_DEVICES] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return nullptr;
@@ -90,6 +93,20 @@ void prof_end(int id, hipStream_t s) {
 }  // namespace casmtr
 
 using namespace casmtr;
+
+// Test hook: after a device synchronisation every work counter of the current device must be zero again (each dynamic-schedule launch
+// leaves its slot as it found it).  -> number of non-zero ints, 0 also when no counters were ever allocated, < 0 on a HIP error.
+extern "C" int casmtr_debug_work_counters_nonzero(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return -1;
+    int* p = __atomic_load_n(&g_work_base[dev], __ATOMIC_ACQUIRE);
+    if (!p) return 0;
+    std::vector<int> h((size_t)WORK_SLOT_INTS * WORK_NSLOT);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), p, h.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int n = 0;
+    for (int v : h) n += v != 0;
+    return n;
+}
 
 // Scope names = stages of the path (several kernels can serve a stage, depending on shape and CASMTR_*_KERNEL selectors);
 // casmtr_prof_symbol() names the kernel that actually ran.

@@ -23,6 +23,9 @@ typedef void* casmtr_stream_t; /* hipStream_t */
 
 #define CASMTR_ABI_VERSION 7
 int casmtr_abi_version(void);
+/* Test hook (round 6): the kernels with a dynamic item schedule claim work from per-XCD counters that every launch leaves zeroed;
+ * synchronises the device and returns the number of non-zero counter words (0 = consistent; < 0: HIP error).                     */
+int casmtr_debug_work_counters_nonzero(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Drop-in primitives: one entry point per pybind function of the reference's three extensions.
