@@ -559,23 +559,26 @@ __global__ __launch_bounds__(256, 2) void ds_flagged_kernel(const float* __restr
         const float* ap = (cols ? f1 : f0) + ((size_t)b * NL + gl) * C + half * 16;
         const char* bp = reinterpret_cast<const char*>(img_blk) + ((size_t)b * NB_blk + blk) * (size_t)KS32 * 16384 + tid * 16;
         char* const a_dst = As + (half * 2) * 4096 + lrow * 16;
-        f32x4 av[4];
+        // the gathered rows come from anywhere in the pair's features (HBM / Infinity Cache latency): two chunks ahead; the block's image is
+        // L2-resident after its first few items: one chunk ahead
+        f32x4 av[4], avn[4];
         u32x4 bv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             av[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+            avn[i] = KS32 > 1 ? *reinterpret_cast<const f32x4*>(ap + 32 + 4 * i) : av[i];
             bv[i] = *reinterpret_cast<const u32x4*>(bp + 4096 * i);
         }
         const char* fa_base = As + hi * 4096 + (wr * 64 + ln) * 16;   // k16 sub-stage s: + s * 8192; tile ti: + ti * 512; lo part: + 2048
         const char* fb_base = Bs + hi * 4096 + (wc * 64 + ln) * 16;
-        for (int ks = 0; ks < KS32; ++ks) {
+        auto chunk = [&](int ks, f32x4 (&cur)[4]) {   // cur = chunk ks of the gathered rows; refilled with chunk ks + 2 once it is in LDS
             __syncthreads();   // previous chunk fully consumed
 #pragma unroll
             for (int kgl = 0; kgl < 2; ++kgl) {
                 h16x8 vh, vl;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float xn = ldexpf(av[2 * kgl + (c >> 2)][c & 3], -ex);
+                    const float xn = ldexpf(cur[2 * kgl + (c >> 2)][c & 3], -ex);
                     const _Float16 h = (_Float16)xn;
                     vh[c] = h;
                     vl[c] = (_Float16)(xn - (float)h);
@@ -585,12 +588,13 @@ __global__ __launch_bounds__(256, 2) void ds_flagged_kernel(const float* __restr
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Bs + 4096 * i + tid * 16) = bv[i];
+            if (ks + 2 < KS32) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[i] = *reinterpret_cast<const f32x4*>(ap + (ks + 2) * 32 + 4 * i);
+            }
             if (ks + 1 < KS32) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    av[i] = *reinterpret_cast<const f32x4*>(ap + (ks + 1) * 32 + 4 * i);
-                    bv[i] = *reinterpret_cast<const u32x4*>(bp + (size_t)(ks + 1) * 16384 + 4096 * i);
-                }
+                for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const u32x4*>(bp + (size_t)(ks + 1) * 16384 + 4096 * i);
             }
             __syncthreads();
 #pragma unroll
@@ -607,6 +611,10 @@ __global__ __launch_bounds__(256, 2) void ds_flagged_kernel(const float* __restr
                 }
                 if (cols) ds16_mfma12<true>(acc, ah, al, bh, bl); else ds16_mfma12<false>(acc, ah, al, bh, bl);
             }
+        };
+        for (int ks = 0; ks < KS32; ks += 2) {
+            chunk(ks, av);
+            if (ks + 1 < KS32) chunk(ks + 1, avn);
         }
         // ---- the entries, from the accumulators (32x32 C/D layout: column ln, rows (r & 3) + 8 (r >> 2) + 4 hi of each block).  Almost every
         //      entry fails the line's threshold; the few that pass are queued in LDS (over the operand chunk, which is dead now) and handled

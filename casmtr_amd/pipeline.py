@@ -65,12 +65,14 @@ class HotPathConfig:
                                       # the fp32 MFMA chain
     masked: bool = False              # MegaDepth-style padding masks (BASELINE configs[2]): bottom / right up to 20 % padded
     fresh_inputs: bool = True         # every attention layer reads its own q/k/v tensors (False: one shared set, as round 1)
-    paired_layers: object = "coarse"  # False | True | "coarse".  The two directions of a layer are independent in the reference
+    paired_layers: object = "qta"     # False | True | "coarse" | "qta".  The two directions of a layer are independent in the reference
                                       # (transformer.py:295-300 / :549).  "coarse" (default): QTAttB's layout pass and coarsest level run
                                       # once for both directions on the doubled batch, the finer levels once per direction (bit-equal to
                                       # separate calls; 12.02-12.03 against 12.15-12.27 ms per step, round 4).  True: every kernel once on
                                       # the doubled batch (12.18-12.19: the gather kernels lose on 16 pairs what the coarsest level gains).
-                                      # The two directions on two HIP streams instead: 565 against 588 pairs/s (round 3)
+                                      # The two directions on two HIP streams instead: 565 against 588 pairs/s (round 3).  "qta" (default
+                                      # since round 6): all QTAttB levels on the doubled batch, CascadeQTAttB per direction -- with dynamic item
+                                      # claiming the fine levels gain on 16 pairs (2.25 -> 2.22, 1.27 -> 1.23 ms), the cascade kernel still loses
     ds_gemm: str = "split"            # CoarseMatching(gemm=...): 'split' = f16 matrix pipe + exact argmax re-decision (ops.ds_gemm_mode),
                                       # 'exact' = every logit from the fp32 chain; CASMTR_DS_GEMM overrides (bench.py's exact leg)
     implicit_windows: bool = True     # cascade window lists travel as topk_pos [B,N/4,25,2]; the int64 [B,N,100]
