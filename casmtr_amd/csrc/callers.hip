@@ -385,6 +385,173 @@ __global__ __launch_bounds__(256, 3) void linear16_kernel(const Linear16Batch lb
         }
 }
 
+// The same GEMM with the ACTIVATION TILE STATIONARY (round 6, second version).  linear16_kernel reads and splits a 128 x K activation
+// tile once per 128 output columns and per problem: at K = N = 256 the q / k / v projections of a self-attention layer pull the same
+// rows through the L2 twelve times and convert them six times, and every tile pays its own first pass + eight-chunk latency chain
+// (69 us per 86 528 x 256 x 256 problem against 39 us for its bytes).  Here a workgroup owns 64 rows of ONE activation tensor: it reads
+// them once (registers), finds the exponents, splits them into LDS for the whole K (64 KB at K = 256) and then walks every job that
+// uses these rows -- every problem of the launch with this x pointer, every 128-column tile of its weights -- with the prepared weight
+// fragments read from the L2 straight into registers.  x is read from HBM exactly once per launch; nothing else is.
+struct Lin16sBatch {
+    const float* x[LIN_MAXP];           // distinct activation tensors (groups)
+    int first[LIN_MAXP], count[LIN_MAXP];   // group g: problems prob[first[g]] .. + count[g]
+    const char* wimg[LIN_MAXP];         // per problem, in group order
+    const float* wfac[LIN_MAXP];
+    const float* bias[LIN_MAXP];
+    float* y[LIN_MAXP];
+    int qh, qw;
+    unsigned magic_w;
+};
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void linear16s_kernel(const Lin16sBatch lb, int M, int N) {
+    constexpr int KS = K / 32, RB = 64;
+    constexpr int NV = K / 16;   // float4 loads per thread (4 threads per row)
+    extern __shared__ __attribute__((aligned(16))) char lds16s[];
+    char* As = lds16s;                       // [ks][kg 4][hi | lo][64 rows][8 f16]: 8 KB per 32-channel chunk
+    float* facA = reinterpret_cast<float*>(As + KS * 8192);   // [64]
+    const int g = blockIdx.y, i0 = blockIdx.x * RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int hi = lane >> 5, ln = lane & 31;
+    // ---- phase 1: the 64 rows, once.  Thread <-> (row tid / 4, quarter tid % 4 of the channels)
+    {
+        const int row = tid >> 2, qt = tid & 3;
+        const int gi = i0 + row < M ? i0 + row : M - 1;
+        const float* ap = lb.x[g] + (size_t)gi * K + qt * (K / 4);
+        f32x4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+        mx = fmaxf(mx, dpp_f32<0xB1>(mx));   // lane ^ 1
+        mx = fmaxf(mx, dpp_f32<0x4E>(mx));   // lane ^ 2
+        const int e = (mx > 0.f && mx < INFINITY) ? ilogbf(mx) - 9 : 0;   // ds_rownorm_kernel's rule: largest |element| -> [512, 1024)
+        const float sc = ldexpf(1.0f, -e);
+        if (qt == 0) facA[row] = ldexpf(1.0f, e);
+#pragma unroll
+        for (int j = 0; j < NV / 2; ++j) {   // groups of 8 channels: g8 = qt * NV / 2 + j -> chunk g8 / 4, plane kg = g8 % 4
+            const int g8 = qt * (NV / 2) + j;
+            l16_h8 vh, vl;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float xn = v[2 * j + (c >> 2)][c & 3] * sc;   // exact: a power of two
+                const _Float16 h = (_Float16)xn;
+                vh[c] = h;
+                vl[c] = (_Float16)(xn - (float)h);
+            }
+            char* d = As + (g8 >> 2) * 8192 + (g8 & 3) * 2048 + row * 16;
+            *reinterpret_cast<l16_h8*>(d) = vh;
+            *reinterpret_cast<l16_h8*>(d + 1024) = vl;
+        }
+    }
+    // ---- phase 2: every job on these rows.  4 waves = 2 (32 rows) x 2 (64 columns) of the 64 x 128 output tile
+    const int NJB = N / LIN_BN;
+    const char* fa_base = As + hi * 2048 + (wr * 32 + ln) * 16;     // chunk ks: + ks * 8192; k16 stage s: + s * 4096; lo part: + 1024
+    // The weight fragments go from the prepared image (L2-resident: N K 4 bytes per problem) STRAIGHT into registers -- a lane's 16 bytes
+    // of plane (kg = lane / 32, part) of column wc * 64 + tj * 32 + lane % 32 are what the MFMA wants, and a half-wave reads 512 contiguous
+    // bytes: no LDS buffer for B (64 KB + 16 KB + the factors would be 768 bytes over two workgroups per CU) and no barrier in the k-loop.
+    const unsigned b_lane = (unsigned)(hi * 4096 + (wc * 64 + ln) * 16);
+    __syncthreads();   // phase 1 complete
+    for (int pi = 0; pi < lb.count[g]; ++pi) {
+        const int p = lb.first[g] + pi;
+        const float* __restrict__ bias = lb.bias[p];
+        float* __restrict__ Y = lb.y[p];
+        for (int tJ = 0; tJ < NJB; ++tJ) {
+            const int j0 = tJ * LIN_BN;
+            const char* bq = lb.wimg[p] + (size_t)tJ * KS * 16384 + b_lane;   // stage (ks, st): + ks * 16384 + st * 8192; tile tj: + tj * 512; lo: + 2048
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            // k16 stages s = 2 ks + st: stage s + 1's fragments are loaded while stage s multiplies (two register sets; the loop is
+            // unrolled by two so that the set index is a constant -- fully unrolled, the compiler hoists all 16 stages' loads: 255 VGPRs)
+            l16_h8 bh[2][2], bl[2][2];
+            auto loadb = [&](int st, l16_h8 (&h)[2], l16_h8 (&l)[2]) {
+                const char* pb = bq + st * 8192;
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    h[tj] = *reinterpret_cast<const l16_h8*>(pb + tj * 512);
+                    l[tj] = *reinterpret_cast<const l16_h8*>(pb + tj * 512 + 2048);
+                }
+            };
+            auto stage = [&](int st, const l16_h8 (&h)[2], const l16_h8 (&l)[2]) {
+                const char* pa = fa_base + st * 4096;
+                const l16_h8 ah = *reinterpret_cast<const l16_h8*>(pa), al = *reinterpret_cast<const l16_h8*>(pa + 1024);
+                // small terms first (linear16_kernel's / ds_gemm16_kernel's order)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, h[tj], acc[tj], 0, 0, 0);
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, l[tj], acc[tj], 0, 0, 0);
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, h[tj], acc[tj], 0, 0, 0);
+            };
+            loadb(0, bh[0], bl[0]);
+#pragma unroll 1
+            for (int st = 0; st < 2 * KS; st += 2) {
+                loadb(st + 1, bh[1], bl[1]);
+                stage(st, bh[0], bl[0]);
+                if (st + 2 < 2 * KS) loadb(st + 2, bh[0], bl[0]);
+                stage(st + 1, bh[1], bl[1]);
+            }
+            // epilogue of the job: y = acc * 2^e_m * 2^e_n (+ bias)
+            float bj[2], fbv[2];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int cj = wc * 64 + tj * 32 + ln;
+                fbv[tj] = lb.wfac[p][j0 + cj];
+                bj[tj] = bias ? bias[j0 + cj] : 0.f;
+            }
+            if (lb.qw) {   // quad-major rows (see linear_nt_kernel)
+                const int hw = lb.qh * lb.qw, wq = lb.qw >> 1, Lq = (lb.qh >> 1) * wq, Hh = N >> 5;
+                const unsigned b0 = (unsigned)i0 / (unsigned)hw, rem0 = (unsigned)i0 - b0 * (unsigned)hw;   // wave-uniform
+                float* yh[2];
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) yh[tj] = Y + (size_t)((j0 + wc * 64 + tj * 32) >> 5) * Lq * 128 + ln;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (i0 + lr >= M) continue;
+                    unsigned b = b0, pp = rem0 + (unsigned)lr;
+                    while (pp >= (unsigned)hw) { pp -= (unsigned)hw; ++b; }
+                    const unsigned yy = __umulhi(pp, lb.magic_w), xx = pp - yy * (unsigned)lb.qw;
+                    const size_t roff = ((size_t)b * Hh * Lq + (size_t)((yy >> 1) * wq + (xx >> 1))) * 128 + ((yy & 1) * 2 + (xx & 1)) * 32;
+                    const float fa = facA[lr];
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) {
+                        const float v = (acc[tj][r] * fa) * fbv[tj];
+                        yh[tj][roff] = bias ? v + bj[tj] : v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int gr = i0 + lr;
+                    if (gr >= M) continue;
+                    const float fa = facA[lr];
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) {
+                        const float v = (acc[tj][r] * fa) * fbv[tj];
+                        Y[(size_t)gr * N + j0 + wc * 64 + tj * 32 + ln] = bias ? v + bj[tj] : v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_linear16s(const Lin16sBatch& lb, int ngroups, int M, int N, hipStream_t s) {
+    constexpr size_t lds = (K / 32) * 8192 + 64 * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear16s_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    prof_symbol_args(CASMTR_PROF_LINEAR, "<%d>", K);
+    CASMTR_LAUNCH_TIMED(CASMTR_PROF_LINEAR, linear16s_kernel<K>, dim3((unsigned)((M + 63) / 64), (unsigned)ngroups), dim3(256), lds, s, lb, M, N);
+    CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" size_t casmtr_linear_split_prep_bytes(int N, int K) {
     return (N > 0 && K > 0 && N % LIN_BN == 0 && K % LIN_BK == 0) ? (size_t)N * K * 4 + (size_t)N * 4 : 0;   // image (2 f16 per element), then fac[N]
 }
@@ -408,6 +575,29 @@ extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const*
         lb.qh = h; lb.qw = w_;
     }
     hipStream_t s = (hipStream_t)stream;
+    const char* ev = getenv("CASMTR_LINEAR16");   // "tile": the first split kernel (one workgroup per 128 x 128 output tile), for A/B
+    if ((K == 256 || K == 128) && !(ev && ev[0] == 't')) {   // activation-stationary kernel: problems grouped by activation tensor
+        Lin16sBatch sb{};
+        sb.qh = lb.qh; sb.qw = lb.qw; sb.magic_w = lb.magic_w;
+        int ng = 0, np = 0;
+        bool used[LIN_MAXP] = {false, false, false, false};
+        for (int i = 0; i < nprob; ++i) {
+            if (used[i]) continue;
+            sb.x[ng] = x[i]; sb.first[ng] = np;
+            for (int j = i; j < nprob; ++j) {
+                if (used[j] || x[j] != x[i]) continue;
+                used[j] = true;
+                sb.wimg[np] = reinterpret_cast<const char*>(wprep[j]);
+                sb.wfac[np] = reinterpret_cast<const float*>(sb.wimg[np] + (size_t)N * K * 4);
+                sb.bias[np] = bias ? bias[j] : nullptr;
+                sb.y[np] = y[j];
+                ++np;
+            }
+            sb.count[ng] = np - sb.first[ng];
+            ++ng;
+        }
+        return K == 256 ? launch_linear16s<256>(sb, ng, M, N, s) : launch_linear16s<128>(sb, ng, M, N, s);
+    }
     for (int i = 0; i < nprob; ++i) {
         lb.x[i] = x[i];
         lb.wimg[i] = reinterpret_cast<const char*>(wprep[i]);

@@ -246,10 +246,13 @@ def _rows(kind, g, M, K):
 
 @pytest.mark.parametrize("kind", ["randn", "scaled", "sparse"])
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (5408 + 37, 256, 256), (300, 256, 128), (128, 128, 256)])
-def test_linear_split_error_bound(kind, M, N, K):
+@pytest.mark.parametrize("kernel", ["stationary", "tile"])
+def test_linear_split_error_bound(kind, M, N, K, kernel, monkeypatch):
     """|y_split - y_exact_chain| <= 2^-15 |x_m| |w_n| for every output (the budget derived in csrc/callers.hip), measured with a factor to
     spare; against float64 the split is as close as the fp32 chain itself.  Ragged M (rows beyond the last full 128-row tile), with bias."""
     from casmtr_amd import ops
+    if kernel == "tile":   # the first split kernel (one workgroup per 128 x 128 output tile); default: activation-stationary
+        monkeypatch.setenv("CASMTR_LINEAR16", "tile")
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x, w = _rows(kind, g, M, K), _rows("randn" if kind == "sparse" else kind, g, N, K) * 0.05
     b = torch.randn((N,), generator=g)
@@ -330,7 +333,7 @@ def test_blocks_with_split_projections(monkeypatch):
             syms = _lib.prof_symbols()
             _lib.prof_read()
             _lib.prof_enable(False)
-            assert ("linear16_kernel" in (syms.get("linear_nt") or "")) == (gm == "split"), (route, gm, syms.get("linear_nt"))
+            assert ("linear16" in (syms.get("linear_nt") or "")) == (gm == "split"), (route, gm, syms.get("linear_nt"))
         for a, b_, what in zip(outs["exact"], outs["split"], ("QuadtreeAttention", "CascadeQuadtreeAttention")):
             # the projections differ by ~1e-7 relative; a top-k near-tie decided the other way moves single tokens further
             d = (a - b_).abs()
