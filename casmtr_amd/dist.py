@@ -123,8 +123,12 @@ class MatchGatherer:
     add() and flush() are COLLECTIVE: every rank calls them the same number of times (a rank that holds lists while another one
     does not would deadlock the gather), and lists still held when the object is dropped are lost -- call flush() last."""
 
+    MAX_HELD_STEPS = 4096   # a window larger than this (every = "never": one final gather) still exchanges after this many steps, so that a
+                            # long-running caller does not hold every step's lists forever (identical on all ranks: stays collective)
+
     def __init__(self, every=1, pair_offset=0, pairs_per_step=0, dst=0):
         self.every, self.pair_offset, self.pairs_per_step, self.dst = max(1, int(every)), int(pair_offset), int(pairs_per_step), dst
+        self.every = min(self.every, self.MAX_HELD_STEPS)
         if self.every > 1 and self.pairs_per_step <= 0:
             raise ValueError("MatchGatherer(every > 1) needs pairs_per_step > 0: the held steps' pair ids would collapse onto each other")
         self._held = []

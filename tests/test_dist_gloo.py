@@ -208,3 +208,10 @@ def check_mock_line(d, every, steps, warmup, total, world=2):
         assert got["sum_m_bids"] == w["sum_m_bids"], "global pair ids (shard offset + held-step offset)"
         assert abs(got["sum_code"] - w["sum_code"]) < 1e-3 * max(1.0, abs(w["sum_code"]))
     assert max(max(g["counts"]) for g in d["exchanges"]) >= 20000, "the large list travelled"
+
+
+def test_match_gatherer_window_is_bounded():
+    """every = 'never' (bench's one final gather) still exchanges after MAX_HELD_STEPS steps: a service loop cannot hold lists forever"""
+    from casmtr_amd import dist as cdist
+    g = cdist.MatchGatherer(every=1 << 30, pairs_per_step=8)
+    assert g.every == cdist.MatchGatherer.MAX_HELD_STEPS
