@@ -488,7 +488,7 @@ extern "C" int casmtr_cascade_attn_quad_fwd(const float* q, const float* key, co
     // 22.0 / 22.0 ms: there the kernel is bound by its memory traffic, not by its instruction stream.  Default: one head per wave
     // (XCD <-> head, the round-3 mapping).
     a.hw = 1;
-    { const char* ev = getenv("CASMTR_CQ_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters(); }
+    { const char* ev = getenv("CASMTR_CQ_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters((hipStream_t)stream); }
     { const char* ev = getenv("CASMTR_CQ_CLAIM"); a.claim = ev && atoi(ev) > 0 ? atoi(ev) : 1; }   // 1 / 2 / 4 / 8: 495 / 503 / 511 / 540 us (12 % random windows)
     { const char* ev = getenv("CASMTR_CQ_HEADS_PER_WAVE"); const int v = ev ? atoi(ev) : 0; if (v >= 1 && v <= nhead && nhead % v == 0 && (8 % (nhead / v)) == 0) a.hw = v; }
     return rel_pos ? launch_cas_quad<true>(a, (hipStream_t)stream) : launch_cas_quad<false>(a, (hipStream_t)stream);

@@ -211,7 +211,7 @@ __device__ __forceinline__ float sum_over_slices8(float x) {
 #define WORK_XCD_INTS 64
 #define WORK_EXIT_OFF 32
 #define WORK_SLOT_INTS (8 * WORK_XCD_INTS)
-int* work_counters();
+int* work_counters(hipStream_t stream);
 // Claim (whole wave active, wave-uniform `doit`): lane 0 adds 1 to the counter, the pre-increment value arrives in `ret` ASYNCHRONOUSLY,
 // like a load: it is valid once a LATER s_waitcnt vmcnt(N) has passed with N <= the number of vector-memory operations issued behind
 // the claim (vmcnt retires in order); read it with work_claimed(ret) behind such a wait.  doit == false: the instruction runs with

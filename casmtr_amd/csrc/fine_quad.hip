@@ -668,7 +668,7 @@ extern "C" int casmtr_qta_fine_level_quad_fwd(const float* q, const float* key, 
                         magic((unsigned)(w0 / 2), (unsigned long long)a.nquads + 1, &a.magic_wq);
         if (!ok) return CASMTR_ERR_UNSUPPORTED;   // (grids of more than ~10^5 quads per XCD chunk: no shipped configuration)
         const char* ev = getenv("CASMTR_FQ_DYNAMIC");
-        a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters();
+        a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters((hipStream_t)stream);
         const char* ec = getenv("CASMTR_FQ_CLAIM");
         // isolated launches, B = 8 (profiles/r06_dyn_ab.txt): finest level static 211-236 us, 1 / 2 / 4 / 8 / 16 items per claim 360 / 225 /
         // 208-220 / 215-220 / 232-262; middle level static 112-126, 118 / 108-111 / 111-120 / 124-132 / 164-175

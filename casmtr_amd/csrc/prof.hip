@@ -14,7 +14,7 @@ namespace casmtr {
 static constexpr int WORK_NSLOT = 64;
 static int* g_work_base[CASMTR_MAX_DEVICES] = {nullptr};
 
-int* work_counters() {
+int* work_counters(hipStream_t stream) {
     constexpr int NSLOT = WORK_NSLOT;
     int** base = g_work_base;
     static unsigned seq[CASMTR_MAX_DEVICES] = {0};
@@ -22,7 +22,10 @@ int* work_counters() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CASMTR_MAX_DEVICES) return nullptr;
     int* p = __atomic_load_n(&base[dev], __ATOMIC_ACQUIRE);
     if (!p) {
-        // (fails while a stream capture is in progress: the caller then runs its static schedule, and the next eager call allocates)
+        // not while `stream` is being captured into a graph (an allocation would invalidate the capture): the caller then runs its
+        // static schedule, and the next eager call allocates
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
         if (hipMalloc(&p, sizeof(int) * WORK_SLOT_INTS * NSLOT) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         if (hipMemset(p, 0, sizeof(int) * WORK_SLOT_INTS * NSLOT) != hipSuccess) {   // synchronous, once per device
             (void)hipGetLastError();

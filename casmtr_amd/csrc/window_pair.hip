@@ -448,7 +448,7 @@ int casmtr_window_match_pair(const float* fq, const float* fk, const int64_t* tp
     a.sqrtC = (float)sqrt((double)C); a.inv_sqrtC = 1.0f / a.sqrtC; a.T = T; a.invT = 1.0f / T;
     a.B = B; a.h0 = h0; a.w0 = w0; a.h1 = h1; a.w1 = w1; a.nquads = (h0 / 2) * (w0 / 2);
     a.npr = (w0 / 2 + 1) / 2; a.nitems = (h0 / 2) * a.npr;
-    { const char* ev = getenv("CASMTR_WP_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters(); }
+    { const char* ev = getenv("CASMTR_WP_DYNAMIC"); a.ctr = (ev && ev[0] == '0') ? nullptr : work_counters(s); }
     { const char* ev = getenv("CASMTR_WP_CLAIM"); a.claim = ev && atoi(ev) > 0 ? atoi(ev) : 1; }
     return C == 128 ? launch_wm_pair<128, true>(a, s) : launch_wm_pair<64, true>(a, s);
 }
