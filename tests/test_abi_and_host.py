@@ -166,3 +166,65 @@ def test_quad_kernels_isa_guard():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_quad_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_host_tests", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_audit_match_diff_names_causes():
+    """bench.py's parity block prints WHY a match entry differs between the GPU chain and the oracle chain"""
+    import numpy as np
+    from types import SimpleNamespace
+    bench = _load_bench()
+    h, w = 8, 8
+    st = SimpleNamespace(test_thr=0.2, pre_thr=[0.2], nms_window=5)
+    cg = np.full((h * w,), 0.5, np.float32)
+    co = cg.copy()
+    cg[10], co[10] = 0.2000001, 0.1999999              # conf on the threshold: in the GPU list only
+    co[27], co[28] = 0.9000001, 0.9000000              # two confidences of one NMS window within 2e-5: the winner flips
+    cg[27], cg[28] = 0.9000000, 0.9000001
+    pre = [(np.full((4 * 4,), 0.7, np.float32), (4, 4))]
+    res = bench.audit_match_diff({(10, 3), (28, 5)}, {(27, 5)}, cg, co, (h, w), st, pre)
+    by_i = {r["i"]: r for r in res}
+    assert set(by_i) == {10, 27, 28}
+    assert by_i[10]["in"] == "gpu only" and "test_thr" in by_i[10]["cause"][0]
+    assert by_i[27]["in"] == "oracle only" and "NMS" in " ".join(by_i[27]["cause"]) and "NMS" in " ".join(by_i[28]["cause"])
+    res = bench.audit_match_diff({(40, 1)}, set(), cg, co, (h, w), SimpleNamespace(test_thr=0.2, pre_thr=[0.2], nms_window=0), pre)
+    assert res[0]["cause"] == ["UNEXPLAINED"], "an entry with no borderline comparison behind it is reported as such, not explained away"
+
+
+def test_bench_live_traffic_parser(tmp_path, monkeypatch):
+    """bench.measure_traffic_live: two rocprofv3 --pmc passes -> bytes per launch per scope with the gfx950 correction; a failing pass
+    is reported, never raised (the bench line must survive a box without a usable rocprofv3)"""
+    import subprocess
+    bench = _load_bench()
+    calls = []
+
+    def fake_run(cmd, **kw):
+        ctr = cmd[cmd.index("--pmc") + 1]
+        d = cmd[cmd.index("-d") + 1]
+        assert "--no-pmc" in cmd and "--no-extra" in cmd and kw.get("cwd") == "/tmp"
+        os.makedirs(os.path.join(d, "host"), exist_ok=True)
+        with open(os.path.join(d, "host", "1_counter_collection.csv"), "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for v in (100.0, 300.0):
+                f.write(f'"void fine_quad_kernel<1, false, true>(FineQArgs)",{ctr},{v}\n')
+            f.write(f'"void cascade_quad_kernel<false>(CasQArgs)",{ctr},1000.0\n')
+            f.write(f'"void at::native::something()",{ctr},5.0\n')
+        calls.append(ctr)
+        return subprocess.CompletedProcess(cmd, 0, "", "")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: True)
+    out, note = bench.measure_traffic_live(["--config", "4c"])
+    assert calls == ["FETCH_SIZE", "WRITE_SIZE"] and "measured in this run" in note
+    assert out["qta_fine_level[lists<=64]"] == 2 * 200 * 1024 + 200 * 1024 and out["cascade_attn"] == 3 * 1000 * 1024
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 1, "", "boom"))
+    out, note = bench.measure_traffic_live([])
+    assert out == {} and "failed" in note
