@@ -100,7 +100,7 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
 //   3. row statistics over the wave's 64 columns: 32-row slabs through a wave-private LDS region, lane <-> row;
 //   4. the two waves sharing rows / columns combine through a small LDS exchange -> one partial per 128-wide block.
 // SPLIT: x = acc * facA[row] * facB[col] (factors staged in LDS), no row argmax (the indices come from the exact re-decision of
-// the near-tie candidates), but the column maxima of the eight 16-row groups of the block are kept (cg_m); otherwise
+// the near-tie candidates); otherwise
 // x = acc / T and the first argmax is tracked in both directions.
 // `scratch` >= 4*32*65 + 2*2*128*3 floats, free of live data (caller has synchronised the workgroup).
 template <bool RECIP, bool SPLIT, bool STORE = true>   // STORE == false (split path only): the matrix is not written

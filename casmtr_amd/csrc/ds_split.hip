@@ -12,7 +12,8 @@
 //      the chain itself  (C + 3) 2^-24  (worst case, C = 256: 1.55e-5)      split 3 x 2^-22 = 7.2e-7
 //      48 fp32 MFMA accumulations + 2 scalings  <= 50 x 2^-23 = 6.0e-6      => e_ij = 2^-15 |a_i| |b_j| / (C T)  (3.05e-5)
 // An entry can be its row's exact maximum only if its approximate logit is >= max~ - 2 e_i (e_i with max_j |b_j|): those are
-// the row's candidates (ds_conf_kernel<true> collects them while it streams the matrix anyway); a row with one candidate has
+// the row's candidates (collected by pass 2: ds_flagged_kernel on the recomputed flagged segments, or ds_conf_kernel<true> where the
+// matrix is stored and streamed); a row with one candidate has
 // its argmax, a row with several re-evaluates them with the exact chain here (ds_fix_kernel) -- about 0.4 % of the rows on
 // random features.  Sums, probabilities and confidences use the approximate logits (relative error of exp < 1e-4 x |a||b|/(C T) x 0.3).
 #include <stdlib.h>
@@ -436,7 +437,7 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
 //                        of ds_split_kernel's image) against the block's contiguous image of B, ds_gemm16_kernel's MFMA sequence and
 //                        scaling -- the logits are
 //                        bit-identical to what the GEMM saw (the segment maxima it left are maxima of exactly these values); then
-//                        ds_sparse's per-entry logic from the accumulator registers: candidate lists, confidences of the entries
+//                        the per-entry logic of rounds 3-5's sparse pass from the accumulator registers: candidate lists, confidences of the entries
 //                        above tau, packed best-of-row / best-of-column atomics, borderline list.  Column items are the transposed
 //                        problem (listed columns gathered out of B's image against a row block of A; the two cross products issued in
 //                        swapped order so that every accumulator again sees the GEMM's sequence) and only collect index candidates:

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
     const float* rmax = w.rmax + (size_t)b * L + i0;   // wave-uniform
     const float* rsum = w.rsum + (size_t)b * L + i0;
     const float* rthr = CAND ? w.rthr + (size_t)b * L + i0 : nullptr;
-    // CAND: borderline entries for the exact re-decision of the match list (ds_split.hip: ds_xdecide_launch; same rule as ds_sparse_kernel)
+    // CAND: borderline entries for the exact re-decision of the match list (ds_split.hip: ds_xdecide_launch; same rule as ds_flagged_kernel)
     const float keep = CAND ? 1.0f - 2.0f * ds_conf_band(kthr, w.namax[b], w.nbmax[b]) : 0.f, cmin = 0.9f * thr;
     float* base = sim + ((size_t)b * L + i0) * S + j;
     constexpr int RU = 4;  // rows in flight per lane
