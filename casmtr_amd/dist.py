@@ -26,7 +26,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CASMTR_DIST_BACKEND=gloo: the collectives run over gloo on host copies although the data lives on GPUs -- lets several
+            # ranks SHARE one device (RCCL refuses that), i.e. a one-GPU box can run the real N > 1 flow end to end (tests)
+            backend = os.environ.get("CASMTR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -70,7 +72,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     if not is_dist() or not params:
         return
     flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-    dist.broadcast(flat, src=src)
+    if dist.get_backend() == "gloo" and flat.is_cuda:
+        host = flat.cpu()
+        dist.broadcast(host, src=src)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src)
     off = 0
     with torch.no_grad():
         for p in params:
@@ -89,6 +96,8 @@ def gather_matches(out, pairs_per_rank=None, dst: int = 0, pair_offset=None):
     if not is_dist():
         return {"mk": mk, "m_bids": bids, "n_total": int(mk.shape[0]), "counts": [int(mk.shape[0])]}
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo" and mk.is_cuda:   # gloo gathers host tensors (see init_from_env)
+        mk, bids = mk.cpu(), bids.cpu()
     dev = mk.device
     cnt = torch.tensor([mk.shape[0]], dtype=torch.int64, device=dev)
     all_cnt = torch.zeros(world, dtype=torch.int64, device=dev)

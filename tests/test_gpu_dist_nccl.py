@@ -55,3 +55,29 @@ def test_mock_device_cuda_single_rank_forced_rccl():
     want = _expected_exchanges(5, 1, 4, 1, 3)
     assert [g["counts"] for g in d["exchanges"]] == [w["counts"] for w in want]
     assert [g["sum_m_bids"] for g in d["exchanges"]] == [w["sum_m_bids"] for w in want]
+
+
+def _bench_line(extra, env=None, timeout=900):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--batch", "1", "--no-extra", "--no-cpu-baseline"] + extra
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CASMTR_FORCE_DIST"):
+        e.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_the_gpu_over_gloo_with_the_real_hot_path():
+    """The whole N > 1 flow with the REAL kernels on a one-GPU box: `python bench.py --gpus 2` (self-launched) with
+    CASMTR_DIST_BACKEND=gloo puts both ranks on cuda:0 (RCCL would refuse to share a device; gloo carries host copies): each rank runs
+    its own pair through the HIP hot path, rank 0's parameters are broadcast, the match lists are gathered to rank 0 after every step.
+    Each rank's list must be exactly what a single process computes for that rank's inputs (seed 1234 + rank) with rank 0's parameters."""
+    two = _bench_line(["--gpus", "2", "--gather-every", "1"], env={"CASMTR_DIST_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["config"]["pairs_per_step"] == 2 and two["scaling"] == "weak"
+    per_rank = two["config"]["matches_gathered_per_rank"]
+    assert len(per_rank) == 2 and sum(per_rank) == two["config"]["matches_gathered"] and min(per_rank) > 100
+    for r in (0, 1):
+        one = _bench_line(["--gpus", "1", "--seed-offset", str(r)] if r else ["--gpus", "1"])
+        assert one["config"]["matches_last_step"] == per_rank[r], f"rank {r}: gathered {per_rank[r]}, single process {one['config']['matches_last_step']}"
