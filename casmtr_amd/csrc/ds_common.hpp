@@ -67,22 +67,22 @@ static inline size_t ds_carve(DsWs* w, char* base, int B, int L, int S, int C) {
     CARVE(rmax, float, (size_t)B * L); CARVE(rsum, float, (size_t)B * L);
     CARVE(cmax, float, (size_t)B * S); CARVE(csum, float, (size_t)B * S);
     CARVE(rbest, unsigned long long, (size_t)B * L); CARVE(cbest, unsigned long long, (size_t)B * S);
+    CARVE(fl_rn, int, (size_t)B * NJB); CARVE(fl_cn, int, (size_t)B * NIB); CARVE(fl_tn, int, 4);
     if (C > 0) {
         CARVE(rcnt, int, (size_t)B * L); CARVE(ccnt, int, (size_t)B * S);
         CARVE(namax, unsigned, B); CARVE(nbmax, unsigned, B); CARVE(ovf, int, 1);
         CARVE(xcnt, int, 4); CARVE(xln, int, 2 * (size_t)B); CARVE(rneed, unsigned char, (size_t)B * L); CARVE(cneed, unsigned char, (size_t)B * S);
         CARVE(rdec, unsigned char, (size_t)B * L);
-        CARVE(fl_rn, int, (size_t)B * NJB); CARVE(fl_cn, int, (size_t)B * NIB); CARVE(fl_tn, int, 4);
     }
     if (w) w->zero_end = base + off;
     CARVE(flags, unsigned char, (size_t)B * L); CARVE(jsel, int64_t, (size_t)B * L); CARVE(csel, float, (size_t)B * L);
     CARVE(blk, int, ((size_t)B * L + 1023) / 1024 + 8);
+    CARVE(fl_r, int, (size_t)B * NJB * L); CARVE(fl_c, int, (size_t)B * NIB * S); CARVE(fl_t, int, 2 * (size_t)B * NJB * NIB + 8);
     if (C > 0) {
         CARVE(na, float, (size_t)B * Lp); CARVE(nb, float, (size_t)B * Sp);
         CARVE(fa, float, (size_t)B * Lp); CARVE(fb, float, (size_t)B * Sp);
         CARVE(exA, int, (size_t)B * Lp); CARVE(exB, int, (size_t)B * Sp);
         CARVE(rthr, float, (size_t)B * L); CARVE(cthr, float, (size_t)B * S);
-        CARVE(fl_r, int, (size_t)B * NJB * L); CARVE(fl_c, int, (size_t)B * NIB * S); CARVE(fl_t, int, 2 * (size_t)B * NJB * NIB + 8);
         CARVE(rcand, int, (size_t)B * L * DS_CAND_CAP); CARVE(ccand, int, (size_t)B * S * DS_CAND_CAP);
         CARVE(xent, int, 2 * DS_X_CAP); CARVE(xcf, float, DS_X_CAP); CARVE(rlist, int, (size_t)B * DS_XL_PCAP); CARVE(clist, int, (size_t)B * DS_XL_PCAP);
         CARVE(rdec_j, int, (size_t)B * L); CARVE(rdec_cf, float, (size_t)B * L);
@@ -246,6 +246,7 @@ int ds_split_launch(const float* feat0, const float* feat1, const uint8_t* mask0
                     int C, float temperature, int recip, hipStream_t s);
 int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, const DsWs& w, int B, int L, int S, int C, int store, hipStream_t s);
 int ds_flagged_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float thr, float kthr, hipStream_t s);
+int ds_flag_lists_launch(const DsWs& w, int B, int L, int S, float thr, int exact_rows_only, hipStream_t s);
 int ds_fix_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float temperature, int recip,
                   int64_t* next_idx01, int64_t* next_idx10, hipStream_t s);
 int ds_xdecide_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L,

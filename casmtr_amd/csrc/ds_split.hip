@@ -447,7 +447,7 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
 #define DS_FL_ROWS 128
 #define DS_FL_QCAP 4000   // entries of a tile that pass their line's threshold (8 bytes each, in the 32 KB of the dead operand chunk)
 #define DS_FL_CHUNK 8
-__global__ __launch_bounds__(256) void ds_flagscan_kernel(DsWs w, int B, int L, int S, int NJB, int NIB, float thr) {
+__global__ __launch_bounds__(256) void ds_flagscan_kernel(DsWs w, int B, int L, int S, int NJB, int NIB, float thr, int exact_rows_only) {
     // thread <-> (line, chunk of 8 segments): the chunk's 8 maxima are in flight together; a wave's lanes share (pair, segment), so the
     // compiler's wave-aggregated atomic hands out the list slots
     const int RCH = (NJB + DS_FL_CHUNK - 1) / DS_FL_CHUNK, CCH = (NIB + DS_FL_CHUNK - 1) / DS_FL_CHUNK;
@@ -457,8 +457,9 @@ __global__ __launch_bounds__(256) void ds_flagscan_kernel(DsWs w, int B, int L, 
         const int b = blk / (RCH * RB), ch = (blk / RB) % RCH, i = (blk % RB) * 256 + threadIdx.x;
         if (i >= L) return;
         const size_t o = (size_t)b * L + i;
-        const float rm = w.rmax[o], rs = w.rsum[o], rt = w.rthr[o];
-        const float lim = fminf(rt, rm + __logf(thr * rs) - 1e-2f);
+        // exact path (matching.hip: ds_eflagged_kernel): only entries that can exceed thr matter (x > tau, strictly, as in ds_conf_kernel)
+        const float rm = w.rmax[o], rs = w.rsum[o], tau = rm + __logf(thr * rs) - 1e-2f;
+        const float lim = exact_rows_only ? __uint_as_float(__float_as_uint(tau) + (tau >= 0.f ? 1u : -1u)) : fminf(w.rthr[o], tau);
         float mv[DS_FL_CHUNK];
 #pragma unroll
         for (int k = 0; k < DS_FL_CHUNK; ++k) mv[k] = w.rp_m[((size_t)b * NJB + min(ch * DS_FL_CHUNK + k, NJB - 1)) * L + i];
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void ds_flagscan_kernel(DsWs w, int B, int L, 
         return;
     }
     blk -= B * RCH * RB;
-    if (blk < B * CCH * CB) {
+    if (!exact_rows_only && blk < B * CCH * CB) {
         const int b = blk / (CCH * CB), ch = (blk / CB) % CCH, j = (blk % CB) * 256 + threadIdx.x;
         if (j >= S) return;
         const float ct = w.cthr[(size_t)b * S + j];
@@ -698,12 +699,18 @@ __global__ __launch_bounds__(256, 2) void ds_flagged_kernel(const float* __restr
     }
 }
 
-int ds_flagged_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float thr, float kthr, hipStream_t s) {
+int ds_flag_lists_launch(const DsWs& w, int B, int L, int S, float thr, int exact_rows_only, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const int nscan = B * ((NJB + DS_FL_CHUNK - 1) / DS_FL_CHUNK) * ((L + 255) / 256) + B * ((NIB + DS_FL_CHUNK - 1) / DS_FL_CHUNK) * ((S + 255) / 256);
-    hipLaunchKernelGGL(ds_flagscan_kernel, dim3(nscan), dim3(256), 0, s, w, B, L, S, NJB, NIB, thr);
+    hipLaunchKernelGGL(ds_flagscan_kernel, dim3(nscan), dim3(256), 0, s, w, B, L, S, NJB, NIB, thr, exact_rows_only);
     hipLaunchKernelGGL(ds_flagtiles_kernel, dim3((B * (NJB + NIB) + 255) / 256), dim3(256), 0, s, w, B * NJB, B * NIB);
     CASMTR_CHECK_LAUNCH();
+    return 0;
+}
+
+int ds_flagged_launch(const float* feat0, const float* feat1, const DsWs& w, int B, int L, int S, int C, float thr, float kthr, hipStream_t s) {
+    const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
+    if (const int r = ds_flag_lists_launch(w, B, L, S, thr, 0, s)) return r;
     constexpr size_t lds = 2 * 16384 + 1024 * 4;
     static int resident_tab[CASMTR_MAX_DEVICES] = {0};
     int resident = 0;

@@ -26,7 +26,7 @@ template <bool RECIP>
 __device__ __forceinline__ void ds_gemm_tile(int bx, int nbx, const float* __restrict__ f0, const float* __restrict__ f1,
                                              const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1,
                                              float* __restrict__ sim, const DsWs& w, int L, int S, int C, float sqrtC,
-                                             float inv_sqrtC, float T, float invT, int NJB, int NIB) {
+                                             float inv_sqrtC, float T, float invT, int NJB, int NIB, int store) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // As[128][33] | Bs[128][33], then epilogue scratch
     float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
     float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
@@ -85,7 +85,8 @@ __device__ __forceinline__ void ds_gemm_tile(int bx, int nbx, const float* __res
         }
     }
     __syncthreads();  // every wave is done reading As/Bs: the region becomes the epilogue's scratch
-    ds_tile_epilogue<RECIP, false>(acc, smem, nullptr, nullptr, mask0, mask1, sim, w, b, tI, tJ, L, S, T, invT, NJB, NIB);
+    if (store) ds_tile_epilogue<RECIP, false, true>(acc, smem, nullptr, nullptr, mask0, mask1, sim, w, b, tI, tJ, L, S, T, invT, NJB, NIB);
+    else ds_tile_epilogue<RECIP, false, false>(acc, smem, nullptr, nullptr, mask0, mask1, sim, w, b, tI, tJ, L, S, T, invT, NJB, NIB);
 }
 
 // One workgroup per tile.  As the split path's fallback (guard != nullptr; runs only when its candidate lists overflowed) the grid
@@ -96,14 +97,14 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
                                                          const uint8_t* __restrict__ mask1, float* __restrict__ sim,
                                                          DsWs w, int L, int S, int C, float sqrtC, float inv_sqrtC,
                                                          float T, float invT, int NJB, int NIB, const int* __restrict__ guard,
-                                                         int ntiles) {
+                                                         int ntiles, int store) {
     if (!guard) {
-        ds_gemm_tile<RECIP>(blockIdx.x, gridDim.x, f0, f1, mask0, mask1, sim, w, L, S, C, sqrtC, inv_sqrtC, T, invT, NJB, NIB);
+        ds_gemm_tile<RECIP>(blockIdx.x, gridDim.x, f0, f1, mask0, mask1, sim, w, L, S, C, sqrtC, inv_sqrtC, T, invT, NJB, NIB, store);
         return;
     }
     if (*guard == 0) return;
     for (int bx = blockIdx.x; bx < ntiles; bx += gridDim.x) {
-        ds_gemm_tile<RECIP>(bx, ntiles, f0, f1, mask0, mask1, sim, w, L, S, C, sqrtC, inv_sqrtC, T, invT, NJB, NIB);
+        ds_gemm_tile<RECIP>(bx, ntiles, f0, f1, mask0, mask1, sim, w, L, S, C, sqrtC, inv_sqrtC, T, invT, NJB, NIB, 1);
         __syncthreads();   // the epilogue's scratch becomes the next tile's operand buffers
     }
 }
@@ -292,6 +293,132 @@ __global__ __launch_bounds__(256) void ds_conf_kernel(float* __restrict__ sim, D
         }
 }
 
+// Pass 2 of the exact path WITHOUT the matrix (round 6; the split path's ds_flagged_kernel has the reasoning).  When conf_matrix is not
+// requested, casmtr_dual_softmax_fwd no longer writes the [B, L, S] matrix: only entries with x > tau = rmax + log(thr rsum) can reach
+// conf > thr, they sit in the (row, 128-column) segments whose maximum -- left in rp_m by the GEMM epilogue -- exceeds tau, and those
+// segments are recomputed here: the listed rows gathered from feat_c0 against the block's rows of feat_c1 with ds_gemm_tile's operand
+// scaling, k-loop and MFMA sequence (the same fmaf chain: bit-identical logits), then ds_conf_kernel's confidence arithmetic and packed
+// best-of-row / best-of-column atomics for the entries above tau.  Entries at or below tau have conf < thr: they can neither be
+// selected nor be the row / column maximum of a selected entry, so the match list is the dense pass's.
+#define DSE_QCAP 4000
+template <bool RECIP>
+__global__ __launch_bounds__(256, 2) void ds_eflagged_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                             const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ mask1, DsWs w,
+                                                             int B, int L, int S, int C, float sqrtC, float inv_sqrtC, float T, float invT,
+                                                             float thr, int NJB) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // As[128][33] | Bs[128][33] (later: the queue), then the per-row tables
+    float (*As)[33] = reinterpret_cast<float (*)[33]>(smem);
+    float (*Bs)[33] = reinterpret_cast<float (*)[33]>(smem + 128 * 33);
+    float* t_tau = smem + 2 * 128 * 33;
+    float *t_rm = t_tau + 128, *t_rinv = t_tau + 256;
+    int* line = reinterpret_cast<int*>(t_tau + 384);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int nitems = w.fl_tn[0];
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int e = w.fl_t[it], lid = e >> 8, tile = e & 255;      // row lists only (ds_flagscan_kernel, exact_rows_only)
+        const int b = lid / NJB, blk = lid - b * NJB, j0 = blk * DS_BN;
+        const int n = w.fl_rn[lid] - tile * 128;
+        const int* list = w.fl_r + (size_t)lid * L + tile * 128;
+        __syncthreads();   // the previous item's tables and queue are no longer read
+        if (tid < 128) {
+            const int li = list[tid < n ? tid : 0];
+            line[tid] = li;
+            const size_t o = (size_t)b * L + li;
+            const float rm = w.rmax[o], rs = w.rsum[o];
+            t_tau[tid] = tid < n ? rm + __logf(thr * rs) - 1e-2f : INFINITY;
+            t_rm[tid] = rm; t_rinv[tid] = 1.0f / rs;
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int lrow = tid >> 1, lc0 = (tid & 1) * 16;
+        const float* ap = f0 + ((size_t)b * L + line[lrow]) * C + lc0;
+        const float* bp = f1 + ((size_t)b * S + (j0 + lrow < S ? j0 + lrow : S - 1)) * C + lc0;
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+            bv[i] = *reinterpret_cast<const f32x4*>(bp + 4 * i);
+        }
+        for (int k0 = 0; k0 < C; k0 += DS_BK) {   // ds_gemm_tile's k-loop
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    As[lrow][lc0 + 4 * i + c] = div_scalar<RECIP>(av[i][c], sqrtC, inv_sqrtC);
+                    Bs[lrow][lc0 + 4 * i + c] = div_scalar<RECIP>(bv[i][c], sqrtC, inv_sqrtC);
+                }
+            if (k0 + DS_BK < C) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = *reinterpret_cast<const f32x4*>(ap + k0 + DS_BK + 4 * i);
+                    bv[i] = *reinterpret_cast<const f32x4*>(bp + k0 + DS_BK + 4 * i);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < DS_BK / 2; ++kk) {
+                const int kc = 2 * kk + (lane >> 5), rr = lane & 31;
+                const float a0 = As[wr * 64 + rr][kc], a1 = As[wr * 64 + 32 + rr][kc];
+                const float b0 = Bs[wc * 64 + rr][kc], b1 = Bs[wc * 64 + 32 + rr][kc];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // operand tiles dead: the region becomes the queue of entries above tau
+        int* qn = reinterpret_cast<int*>(smem);
+        int2* queue = reinterpret_cast<int2*>(smem + 4);
+        if (tid == 0) qn[0] = 0;
+        __syncthreads();
+        int lane_o = lane;   // (opaque: keeps the entries' 64 (row, column) codes from being hoisted out of the item loop, see ds_flagged_kernel)
+        asm volatile("" : "+v"(lane_o));
+        const int hi = lane_o >> 5, ln = lane_o & 31;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int lc = wc * 64 + tj * 32 + ln, gj = j0 + lc;
+            const bool c_ok = gj < S && (!mask1 || mask1[(size_t)b * S + (gj < S ? gj : S - 1)] != 0);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float x = div_scalar<RECIP>(acc[ti][tj][r], T, invT);
+                    if (c_ok && x > t_tau[lr]) {
+                        const int slot = atomicAdd(qn, 1);
+                        if (slot < DSE_QCAP) queue[slot] = make_int2((lr << 8) | lc, __float_as_int(x));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nq = min(qn[0], DSE_QCAP);   // (a tile with more than DSE_QCAP entries above tau: thr * rsum tiny -- the caller keeps such thresholds on the dense pass)
+        for (int q = tid; q < nq; q += 256) {
+            const int2 ent = queue[q];
+            const int lr = ent.x >> 8, j = j0 + (ent.x & 255), li = line[lr];
+            if (mask0 && mask0[(size_t)b * L + li] == 0) continue;     // padding: the GEMM's entry is NEG_FILL there
+            const float x = __int_as_float(ent.y);
+            const size_t o = (size_t)b * L + li, co = (size_t)b * S + j;
+            const float p01 = __expf(x - t_rm[lr]) * t_rinv[lr];
+            const float p10 = __expf(x - w.cmax[co]) * (1.0f / w.csum[co]);
+            const float cf = p10 * p01;                                  // ds_conf_kernel's arithmetic, operation for operation
+            if (cf >= 0.f) {
+                const unsigned long long hk = (unsigned long long)__float_as_uint(cf) << 32;
+                atomicMax(w.rbest + o, hk | (0xFFFFFFFFu - (unsigned)j));
+                atomicMax(w.cbest + co, hk | (0xFFFFFFFFu - (unsigned)li));
+            }
+        }
+    }
+}
+
 // coarse_matching.py:116-132: conf > thr, border removal, mutual maximum BY VALUE, first j per row.
 __global__ __launch_bounds__(256) void ds_flag_kernel(DsWs w, float thr, int border_rm, const int32_t* __restrict__ valid_hw,
                                                       int h0c, int w0c, int h1c, int w1c, int L, int S, int total) {
@@ -420,7 +547,7 @@ __global__ __launch_bounds__(256) void ds_zero_kernel(unsigned long long* __rest
 static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, float temperature,
                            int recip, float thr, int want_conf, float* sim_ws, const DsWs& w, int64_t* next_idx01,
                            float* next_conf01, int64_t* next_idx10, float* next_conf10, int B, int L, int S, int C,
-                           const int* guard, hipStream_t s) {
+                           const int* guard, hipStream_t s, int store = 1) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C);
     const size_t gemm_lds = sizeof(float) * (4 * 32 * 65 + 2 * 2 * 128 * 3);  // >= the 2 x [128][33] operand tiles
@@ -435,10 +562,10 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
         const int gx = guard ? min(ntiles, 768) : ntiles;
         if (recip)
             hipLaunchKernelGGL(ds_gemm_kernel<true>, dim3(gx, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
-                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard, ntiles);
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard, ntiles, store);
         else
             hipLaunchKernelGGL(ds_gemm_kernel<false>, dim3(gx, B), dim3(256), gemm_lds, s, feat0, feat1, mask0, mask1, sim_ws,
-                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard, ntiles);
+                               w, L, S, C, sqrtC, 1.0f / sqrtC, temperature, 1.0f / temperature, NJB, NIB, guard, ntiles, store);
     }
     CASMTR_CHECK_LAUNCH();
     {
@@ -454,6 +581,26 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
         hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest, (size_t)B * L, guard);
         hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.cbest, (size_t)B * S, guard);
         CASMTR_CHECK_LAUNCH();
+    }
+    if (!store) {   // the matrix was not written: pass 2 on the recomputed flagged segments (guard == nullptr here)
+        ProfScope ps(CASMTR_PROF_DS_CONF, s, "ds_flagscan_kernel + ds_flagtiles_kernel + ds_eflagged_kernel (flagged segments recomputed, fp32 chain)");
+        if (const int r = ds_flag_lists_launch(w, B, L, S, thr, 1, s)) return r;
+        constexpr size_t lds = sizeof(float) * (2 * 128 * 33 + 512);
+        static int resident_tab[2][CASMTR_MAX_DEVICES] = {{0}, {0}};
+        int resident = 0;
+        if (recip) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_eflagged_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (const int r = resident_workgroups(resident_tab[1], ds_eflagged_kernel<true>, 256, lds, &resident)) return r;
+            hipLaunchKernelGGL(ds_eflagged_kernel<true>, dim3((unsigned)resident), dim3(256), lds, s, feat0, feat1, mask0, mask1, w, B, L, S, C, sqrtC,
+                               1.0f / sqrtC, temperature, 1.0f / temperature, thr, NJB);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_eflagged_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (const int r = resident_workgroups(resident_tab[0], ds_eflagged_kernel<false>, 256, lds, &resident)) return r;
+            hipLaunchKernelGGL(ds_eflagged_kernel<false>, dim3((unsigned)resident), dim3(256), lds, s, feat0, feat1, mask0, mask1, w, B, L, S, C, sqrtC,
+                               1.0f / sqrtC, temperature, 1.0f / temperature, thr, NJB);
+        }
+        CASMTR_CHECK_LAUNCH();
+        return 0;
     }
     {
         ProfScope ps(guard ? -1 : CASMTR_PROF_DS_CONF, s, "ds_conf_kernel<false>");
@@ -490,8 +637,12 @@ extern "C" int casmtr_dual_softmax_fwd(const float* feat0, const float* feat1, c
     hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest,
                        (size_t)(w.zero_end - reinterpret_cast<char*>(w.rbest)) / sizeof(unsigned long long), (const int*)nullptr);
     CASMTR_CHECK_LAUNCH();
-    int rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf, sim_ws, w, next_idx01, next_conf01,
-                             next_idx10, next_conf10, B, L, S, C, nullptr, s);
+    // want_conf: 0 = neither conf_matrix nor the similarity matrix is written (round 6: pass 2 recomputes the segments that can hold a
+    // match; thr < 1e-3 keeps the streaming pass, whose log(thr rsum) test it replaces), 1 = conf_matrix in sim_ws, 2 = the similarity
+    // matrix stays in sim_ws (tests; the python layer's `want_sim`)
+    const int store = want_conf != 0 || thr < 1e-3f;
+    int rc = ds_exact_passes(feat0, feat1, mask0, mask1, temperature, recip, thr, want_conf == 1, sim_ws, w, next_idx01, next_conf01,
+                             next_idx10, next_conf10, B, L, S, C, nullptr, s, store);
     if (rc) return rc;
     return ds_select(w, thr, border_rm, valid_hw, h0c, w0c, h1c, w1c, b_ids, i_ids, j_ids, mconf, n_matches, B, L, S, s);
 }

@@ -584,8 +584,8 @@ def ds_gemm_mode(requested=None):
 def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=None, mask1=None, valid_hw=None,
                  recip=True, want_conf=True, gemm=None, want_sim=False):
     """CoarseMatching numerics.  Returns a dict; match lists are capacity-sized, `n` is a device int64 scalar.
-    want_conf: conf_matrix [B,L,S] is written.  Without it the split path (gemm='split') does not write the similarity matrix either
-    (its pass 2 recomputes the few segments that matter); want_sim=True asks for it (`sim`: tests).  The exact path always has it."""
+    want_conf: conf_matrix [B,L,S] is written.  Without it neither path writes the similarity matrix (pass 2 recomputes the few
+    segments that matter, round 6); want_sim=True asks for it (`sim`: tests)."""
     _chk(feat0, "feat0"), _chk(feat1, "feat1")
     mask0, mask1 = _u8(mask0), _u8(mask1)
     _chk(valid_hw, "valid_hw", torch.int32)
@@ -611,7 +611,7 @@ def dual_softmax(feat0, feat1, hw0, hw1, temperature, thr, border_rm=0, mask0=No
                        hw1[0], hw1[1], 1 if want_conf else (2 if want_sim else 0), _ptr(sim), _ptr(ws), _ptr(ni01),
                        _ptr(nc01), _ptr(ni10), _ptr(nc10), _ptr(bi), _ptr(ii), _ptr(ji), _ptr(mc),
                        _ptr(n), B, L, S, Cc, _stream()), "dual_softmax_fwd")
-    return dict(conf_matrix=sim if want_conf else None, sim=sim if (not want_conf and (want_sim or not split)) else None, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
+    return dict(conf_matrix=sim if want_conf else None, sim=sim if (not want_conf and want_sim) else None, next_idx_c01=ni01, next_conf_c01=nc01, next_idx_c10=ni10,
                 next_conf_c10=nc10, b_ids=bi, i_ids=ii, j_ids=ji, mconf=mc, n=n)
 
 

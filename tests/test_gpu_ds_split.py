@@ -42,7 +42,7 @@ def test_split_error_bound(ops, kind):
     r = np.random.default_rng(11)
     B, h, w, C, Tm = 2, 24, 20, 256, 0.1      # 480 tokens: 4 row blocks, the last one partial
     f0, f1 = _features(kind, r, B, h * w, C), _features(kind, r, B, h * w, C)
-    ex = ops.dual_softmax(T(f0), T(f1), (h, w), (h, w), Tm, 0.2, want_conf=False, gemm="exact")
+    ex = ops.dual_softmax(T(f0), T(f1), (h, w), (h, w), Tm, 0.2, want_conf=False, gemm="exact", want_sim=True)
     sp = ops.dual_softmax(T(f0), T(f1), (h, w), (h, w), Tm, 0.2, want_conf=False, gemm="split", want_sim=True)
     na = np.linalg.norm(f0.astype(np.float64) / 16.0, axis=2)
     nb = np.linalg.norm(f1.astype(np.float64) / 16.0, axis=2)
@@ -169,9 +169,17 @@ def test_split_with_and_without_the_stored_matrix(ops, hw0, hw1, masked):
             assert torch.equal(out[k], ref[k]), (kw, k)
         for k in ("i_ids", "j_ids", "b_ids", "mconf"):
             assert torch.equal(out[k][:n], ref[k][:n]), (kw, k)
-    ex = ops.dual_softmax(f0, f1, hw0, hw1, 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, gemm="exact", want_conf=False)
-    assert torch.equal(ex["next_idx_c01"], ref["next_idx_c01"]) and torch.equal(ex["next_idx_c10"], ref["next_idx_c10"])
-    assert int(ex["n"].item()) == n and torch.equal(ex["i_ids"][:n], ref["i_ids"][:n]) and torch.equal(ex["j_ids"][:n], ref["j_ids"][:n])
+    # the exact (all-fp32) path likewise: no matrix (recomputed fp32-chain segments) == matrix stored == conf_matrix written, bit for bit
+    exs = [ops.dual_softmax(f0, f1, hw0, hw1, 0.1, 0.2, mask0=m0, mask1=m1, valid_hw=valid, gemm="exact", **kw)
+           for kw in (dict(want_conf=True), dict(want_conf=False), dict(want_conf=False, want_sim=True))]
+    assert exs[1]["sim"] is None and exs[2]["sim"] is not None
+    for ex in exs:
+        assert torch.equal(ex["next_idx_c01"], ref["next_idx_c01"]) and torch.equal(ex["next_idx_c10"], ref["next_idx_c10"])
+        assert int(ex["n"].item()) == n and torch.equal(ex["i_ids"][:n], ref["i_ids"][:n]) and torch.equal(ex["j_ids"][:n], ref["j_ids"][:n])
+    for ex in exs[1:]:
+        for k in ("next_conf_c01", "next_conf_c10"):
+            assert torch.equal(ex[k], exs[0][k]), k
+        assert torch.equal(ex["mconf"][:n], exs[0]["mconf"][:n]) and torch.equal(ex["b_ids"][:n], exs[0]["b_ids"][:n])
 
 
 def test_split_low_threshold_uses_dense_pass(ops):
