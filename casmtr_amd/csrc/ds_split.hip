@@ -106,12 +106,97 @@ __global__ __launch_bounds__(256) void ds_split_kernel(const float* __restrict__
     }
 }
 
+// (1) + (1b) + (2) in ONE launch for both operands (round 6): the three passes above read every feature row twice and cost five launches
+// (0.109 ms per 8-pair call).  Workgroup = 64 rows of one operand, wave w = the k-stages w, w + 4 (32 channels each): the rows arrive
+// once (coalesced, transposed to lane <-> row through the wave's slab, 8 float4 per stage in registers), the waves exchange their
+// partial maxima / sums of squares through LDS, then every wave normalises, splits and writes its stages of the tile image.  The batch
+// maximum of the norms is an atomicMax per workgroup (positive floats order like their bit patterns; namax / nbmax are zeroed with the
+// workspace).  Same exponent rule, same roundings: the image and the factors are ds_rownorm_kernel + ds_split_kernel's, bit for bit.
+template <int KSW>   // k-stages per wave: C / 128
+__global__ __launch_bounds__(256) void ds_prep_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const uint8_t* __restrict__ mask0,
+                                                      const uint8_t* __restrict__ mask1, DsWs w, int L, int S, int C, float inv_sqrtC, float k0a,
+                                                      int NIB, int NJB) {
+    __shared__ float slabs[4 * CASMTR_SLAB_FLOATS];
+    __shared__ float pmx[4][64], pss[4][64];
+    const int side = blockIdx.z, b = blockIdx.y;
+    const int N = side ? S : L, NRB = side ? NJB : NIB;
+    if ((int)blockIdx.x >= 2 * NRB) return;
+    const float* f = side ? f1 : f0;
+    const uint8_t* mask = side ? mask1 : mask0;
+    const int rb = blockIdx.x >> 1, r0 = (blockIdx.x & 1) * 64, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KS = C >> 5;
+    f32x4 x[KSW][8];
+    float mx = 0.f, ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < KSW; ++q) {
+        const int ks = wave + 4 * q;
+        if (ks < KS) {
+            const float* base = f + (size_t)b * N * C + ks * 32;
+            wave_rows32_to_lanes(slabs + wave * CASMTR_SLAB_FLOATS, lane,
+                                 [&](int rr) { const int gi = rb * 128 + r0 + rr; return base + (size_t)(gi < N ? gi : N - 1) * C; }, x[q]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 v = x[q][i];
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        }
+    }
+    pmx[wave][lane] = mx; pss[wave][lane] = ss;
+    __syncthreads();
+    const int gi = rb * 128 + r0 + lane;
+    const bool inr = gi < N;
+    const float m = inr ? fmaxf(fmaxf(pmx[0][lane], pmx[1][lane]), fmaxf(pmx[2][lane], pmx[3][lane])) : 0.f;
+    const int e = (m > 0.f && m < INFINITY) ? ilogbf(m) - 9 : 0;   // largest element -> [512, 1024)
+    if (wave == 0) {
+        const float s2 = (pss[0][lane] + pss[1][lane]) + (pss[2][lane] + pss[3][lane]);
+        const float nr = inr ? sqrtf(s2) * inv_sqrtC * 1.001f : 0.f;   // |a| / sqrt(C), rounded up (covers the fp32 summation and the root)
+        const size_t o = (size_t)b * NRB * 128 + gi;
+        (side ? w.exB : w.exA)[o] = e;
+        const float fv = inr ? ldexpf(side ? 1.0f : k0a, e) : 0.f;
+        (side ? w.fb : w.fa)[o] = (mask && inr && mask[(size_t)b * N + gi] == 0) ? -fv : fv;
+        (side ? w.nb : w.na)[o] = nr;
+        const float wm = wave_max_f32(nr);
+        if (lane == 0) atomicMax((side ? w.nbmax : w.namax) + b, __float_as_uint(wm));
+    }
+    _Float16* img = side ? w.imgB : w.imgA;
+#pragma unroll
+    for (int q = 0; q < KSW; ++q) {
+        const int ks = wave + 4 * q;
+        if (ks < KS) {
+            char* out = reinterpret_cast<char*>(img) + (((size_t)b * NRB + rb) * (size_t)KS + ks) * 16384 + (r0 + lane) * 16;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                h16x8 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float xn = inr ? ldexpf(x[q][2 * kg + (c >> 2)][c & 3], -e) : 0.f;
+                    const _Float16 h = (_Float16)xn;
+                    hi[c] = h;
+                    lo[c] = (_Float16)(xn - (float)h);
+                }
+                *reinterpret_cast<h16x8*>(out + kg * 4096) = hi;
+                *reinterpret_cast<h16x8*>(out + kg * 4096 + 2048) = lo;
+            }
+        }
+    }
+}
+
 int ds_split_launch(const float* feat0, const float* feat1, const uint8_t* mask0, const uint8_t* mask1, const DsWs& w, int B, int L, int S,
                     int C, float temperature, int recip, hipStream_t s) {
     const int NJB = (S + DS_BN - 1) / DS_BN, NIB = (L + DS_BM - 1) / DS_BM;
     const float sqrtC = (float)sqrt((double)C);
     const float k0 = (float)(1.0 / ((double)C * (double)temperature));
     (void)recip;   // the operand pre-scaling mode only matters to the exact chain (ds_fix_kernel)
+    const char* ev = getenv("CASMTR_DS_PREP");   // "3": the three-pass form (tests compare the two)
+    if (!(ev && ev[0] == '3') && C <= 256 && (C & 31) == 0) {
+        const dim3 grid(2 * (NIB > NJB ? NIB : NJB), B, 2);
+        if (C <= 128) hipLaunchKernelGGL(ds_prep_kernel<1>, grid, dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, 1.0f / sqrtC, k0, NIB, NJB);
+        else hipLaunchKernelGGL(ds_prep_kernel<2>, grid, dim3(256), 0, s, feat0, feat1, mask0, mask1, w, L, S, C, 1.0f / sqrtC, k0, NIB, NJB);
+        CASMTR_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NIB * 32, B), dim3(256), 0, s, feat0, mask0, L, C, 1.0f / sqrtC, k0, w.exA, w.fa, w.na, NIB * 128);
     hipLaunchKernelGGL(ds_rownorm_kernel, dim3(NJB * 32, B), dim3(256), 0, s, feat1, mask1, S, C, 1.0f / sqrtC, 1.0f, w.exB, w.fb, w.nb, NJB * 128);
     hipLaunchKernelGGL(ds_nmax_kernel, dim3(B, 2), dim3(256), 0, s, w.na, w.nb, NIB * 128, NJB * 128, w.namax, w.nbmax);

@@ -680,7 +680,7 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     int rc;
     const bool dense = want_conf == 1 || thr < 1e-3f;   // pass 2 streams the stored matrix (needed to write conf_matrix; log(thr rsum) undefined)
     {
-        ProfScope ps(CASMTR_PROF_DS_SPLIT, s, "ds_rownorm_kernel x2 + ds_nmax_kernel + ds_split_kernel x2");
+        ProfScope ps(CASMTR_PROF_DS_SPLIT, s, "ds_prep_kernel (row exponents, norms, f16 split images of both operands)");
         rc = ds_split_launch(feat0, feat1, mask0, mask1, w, B, L, S, C, temperature, recip, s);
     }
     if (rc) return rc;

@@ -299,3 +299,32 @@ def test_split_large_norm_features_fall_back_to_exact(ops, want_conf):
         _assert_same_lists(sp, ex, f"large-norm features, thr = {thr}")
         assert torch.equal(sp["next_idx_c01"], ex["next_idx_c01"]) and torch.equal(sp["next_idx_c10"], ex["next_idx_c10"])
         assert torch.equal(sp["next_conf_c01"], ex["next_conf_c01"]), "the exact passes ran: confidences are the exact path's bit for bit"
+
+
+@pytest.mark.parametrize("C", [64, 128, 192, 256])
+def test_fused_prepass_equals_three_pass(ops, C, monkeypatch):
+    """ds_prep_kernel (one launch: exponents, factors, norms, batch maxima and both tile images) against ds_rownorm_kernel +
+    ds_nmax_kernel + ds_split_kernel: the similarity matrix the GEMM computes from the images, and everything downstream, bit for bit;
+    ragged row blocks, padding masks, badly scaled and all-zero rows"""
+    g = torch.Generator(device="cpu").manual_seed(C)
+    B, hw0, hw1 = 2, (20, 23), (17, 30)
+    L, S = hw0[0] * hw0[1], hw1[0] * hw1[1]
+    f0 = torch.randn((B, L, C), generator=g) * torch.exp(torch.empty((B, L, 1)).uniform_(-8, 8, generator=g))
+    f1 = torch.randn((B, S, C), generator=g)
+    f1[:, :200] = f0[:, :200] + 0.3 * torch.randn((B, 200, C), generator=g)
+    f0[0, 5] = 0.0
+    f1[1, 7] = 0.0
+    m0 = torch.ones((B, L), dtype=torch.bool)
+    m1 = torch.ones((B, S), dtype=torch.bool)
+    m0[:, L - 40:], m1[:, S - 25:] = False, False
+    f0, f1, m0, m1 = f0.to(DEV), f1.to(DEV), m0.to(DEV), m1.to(DEV)
+    outs = {}
+    for mode in ("3", "1"):
+        monkeypatch.setenv("CASMTR_DS_PREP", mode)
+        outs[mode] = [ops.dual_softmax(f0, f1, hw0, hw1, 0.1, 0.2, mask0=mm0, mask1=mm1, want_conf=False, want_sim=True, gemm="split")
+                      for mm0, mm1 in ((None, None), (m0, m1))]
+    for a, b in zip(outs["3"], outs["1"]):
+        for k in ("sim", "next_idx_c01", "next_idx_c10", "next_conf_c01", "next_conf_c10"):
+            assert torch.equal(a[k], b[k]), k
+        n = int(a["n"].item())
+        assert int(b["n"].item()) == n and torch.equal(a["i_ids"][:n], b["i_ids"][:n]) and torch.equal(a["mconf"][:n], b["mconf"][:n])
