@@ -112,14 +112,32 @@ __global__ __launch_bounds__(256, 3) void ds_gemm_kernel(const float* __restrict
 // combine block partials -> per row/col (max, sum, first argmax); next_conf = softmax value at the argmax = 1/sum.
 // Split path (pa == nullptr): no argmax here; instead the near-tie threshold of the row / column: every entry whose exact logit
 // can equal the exact maximum has an approximate logit >= max~ - 2 e, e = 2^-15 |a_i| max_j |b_j| / (C T) (ds_split.hip).
-__global__ __launch_bounds__(256) void ds_reduce_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
-                                                        const int* __restrict__ pa, int nblk, int N, int total,
-                                                        float* __restrict__ omax, float* __restrict__ osum,
-                                                        int64_t* __restrict__ oidx, float* __restrict__ oconf,
-                                                        const float* __restrict__ nrm, int npad, const unsigned* __restrict__ other_max,
-                                                        float kthr, float* __restrict__ othr, const int* __restrict__ guard) {
+struct DsReduceSide {   // one direction of ds_reduce_kernel: rows (blocks = column blocks) or columns
+    const float *pm, *ps;
+    const int* pa;
+    int nblk, N, total;
+    float *omax, *osum;
+    int64_t* oidx;
+    float* oconf;
+    const float* nrm;
+    int npad;
+    const unsigned* other_max;
+    float* othr;
+};
+// both directions in one launch (round 6: two launches of ~20 us each, plus two more that exit at once in the guarded fallback)
+__global__ __launch_bounds__(256) void ds_reduce_kernel(const DsReduceSide r0, const DsReduceSide r1, float kthr, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb0 = (r0.total + 255) / 256;
+    const bool second = (int)blockIdx.x >= nb0;
+    const DsReduceSide& R = second ? r1 : r0;
+    const float *pm = R.pm, *ps = R.ps;
+    const int* pa = R.pa;
+    const int nblk = R.nblk, N = R.N, total = R.total, npad = R.npad;
+    float *omax = R.omax, *osum = R.osum, *oconf = R.oconf, *othr = R.othr;
+    int64_t* oidx = R.oidx;
+    const float* nrm = R.nrm;
+    const unsigned* other_max = R.other_max;
+    const int t = ((int)blockIdx.x - (second ? nb0 : 0)) * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int b = t / N, i = t % N;
     const size_t base = (size_t)b * nblk * N + i;
@@ -569,17 +587,15 @@ static int ds_exact_passes(const float* feat0, const float* feat1, const uint8_t
     }
     CASMTR_CHECK_LAUNCH();
     {
-        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel x2");
-        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L,
-                           w.rmax, w.rsum, next_idx01, next_conf01, nullptr, 0, nullptr, 0.f, nullptr, guard);
-        CASMTR_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, w.cp_a, NIB, S, B * S,
-                           w.cmax, w.csum, next_idx10, next_conf10, nullptr, 0, nullptr, 0.f, nullptr, guard);
+        ProfScope ps(guard ? -1 : CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel (rows + columns)");
+        const DsReduceSide rr{w.rp_m, w.rp_s, w.rp_a, NJB, L, B * L, w.rmax, w.rsum, next_idx01, next_conf01, nullptr, 0, nullptr, nullptr};
+        const DsReduceSide rc{w.cp_m, w.cp_s, w.cp_a, NIB, S, B * S, w.cmax, w.csum, next_idx10, next_conf10, nullptr, 0, nullptr, nullptr};
+        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256 + (B * S + 255) / 256), dim3(256), 0, s, rr, rc, 0.f, guard);
     }
     CASMTR_CHECK_LAUNCH();
-    if (guard) {   // rbest / cbest hold the split pass's (invalid) results
-        hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest, (size_t)B * L, guard);
-        hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.cbest, (size_t)B * S, guard);
+    if (guard) {   // rbest / cbest (adjacent in the workspace) hold the split pass's (invalid) results
+        hipLaunchKernelGGL(ds_zero_kernel, dim3(256), dim3(256), 0, s, w.rbest,
+                           (size_t)((w.cbest + (size_t)B * S) - w.rbest), guard);
         CASMTR_CHECK_LAUNCH();
     }
     if (!store) {   // the matrix was not written: pass 2 on the recomputed flagged segments (guard == nullptr here)
@@ -692,12 +708,10 @@ extern "C" int casmtr_dual_softmax_split_fwd(const float* feat0, const float* fe
     if (rc) return rc;
     const float kthr = 6.103515625e-05f / temperature;   // 2 e = 2^-14 |a_i|/sqrtC max|b_j|/sqrtC / T
     {
-        ProfScope ps(CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel x2");
-        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, w.rp_m, w.rp_s, nullptr, NJB, L, B * L,
-                           w.rmax, w.rsum, next_idx01, next_conf01, w.na, NIB * DS_BM, w.nbmax, kthr, w.rthr, nullptr);
-        CASMTR_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, w.cp_m, w.cp_s, nullptr, NIB, S, B * S,
-                           w.cmax, w.csum, next_idx10, next_conf10, w.nb, NJB * DS_BN, w.namax, kthr, w.cthr, nullptr);
+        ProfScope ps(CASMTR_PROF_DS_REDUCE, s, "ds_reduce_kernel (rows + columns)");
+        const DsReduceSide rr{w.rp_m, w.rp_s, nullptr, NJB, L, B * L, w.rmax, w.rsum, next_idx01, next_conf01, w.na, NIB * DS_BM, w.nbmax, w.rthr};
+        const DsReduceSide rc{w.cp_m, w.cp_s, nullptr, NIB, S, B * S, w.cmax, w.csum, next_idx10, next_conf10, w.nb, NJB * DS_BN, w.namax, w.cthr};
+        hipLaunchKernelGGL(ds_reduce_kernel, dim3((B * L + 255) / 256 + (B * S + 255) / 256), dim3(256), 0, s, rr, rc, kthr, nullptr);
         CASMTR_CHECK_LAUNCH();
     }
     {
