@@ -58,6 +58,7 @@ SIGNATURES = {
     "casmtr_linear_split_prep_bytes": (_SZ, [_I, _I]),
     "casmtr_linear_split_prep": (_I, [_P, _P, _I, _I, _P]),
     "casmtr_linear_split_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "casmtr_linear_split_pyramid_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "casmtr_dwconv3x3_tokens_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "casmtr_layer_norm_fwd": (_I, [_P, _P, _P, _P, _P, _LL, _I, _F, _P]),
     "casmtr_window_attn_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
@@ -148,7 +149,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if l.casmtr_abi_version() != 7:
+        if l.casmtr_abi_version() != 8:
             raise RuntimeError("libcasmtr_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -9,6 +9,7 @@
 // pooled = (((a + b) + c) + d) * 0.25 in (row, col) order of the 2x2 window (torch's avg_pool2d accumulation order).
 #include "common.hpp"
 #include "../../include/casmtr_hip.h"
+#include "linear_pc.hpp"
 
 using namespace casmtr;
 
@@ -401,6 +402,7 @@ struct Lin16sBatch {
     float* y[LIN_MAXP];
     int qh, qw;
     unsigned magic_w;
+    int xflags;                         // experiment switches (CASMTR_LIN_FLAGS, tools/lin_time.py): 1 no stores, 2 no MFMAs, 4 rows not loaded
 };
 
 template <int K>
@@ -419,8 +421,13 @@ __global__ __launch_bounds__(256, 2) void linear16s_kernel(const Lin16sBatch lb,
         const int gi = i0 + row < M ? i0 + row : M - 1;
         const float* ap = lb.x[g] + (size_t)gi * K + qt * (K / 4);
         f32x4 v[NV];
+        if (lb.xflags & 4) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+            for (int i = 0; i < NV; ++i) v[i] = f32x4{(float)tid, 1.f, 2.f, (float)i};
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+        }
         float mx = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void linear16s_kernel(const Lin16sBatch lb,
             };
             loadb(0, bh[0], bl[0]);
 #pragma unroll 1
-            for (int st = 0; st < 2 * KS; st += 2) {
+            for (int st = 0; st < ((lb.xflags & 2) ? 2 : 2 * KS); st += 2) {
                 loadb(st + 1, bh[1], bl[1]);
                 stage(st, bh[0], bl[0]);
                 if (st + 2 < 2 * KS) loadb(st + 2, bh[0], bl[0]);
@@ -503,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void linear16s_kernel(const Lin16sBatch lb,
                 fbv[tj] = lb.wfac[p][j0 + cj];
                 bj[tj] = bias ? bias[j0 + cj] : 0.f;
             }
+            if ((lb.xflags & 1) && acc[0][0] != 12345.678f) continue;
             if (lb.qw) {   // quad-major rows (see linear_nt_kernel)
                 const int hw = lb.qh * lb.qw, wq = lb.qw >> 1, Lq = (lb.qh >> 1) * wq, Hh = N >> 5;
                 const unsigned b0 = (unsigned)i0 / (unsigned)hw, rem0 = (unsigned)i0 - b0 * (unsigned)hw;   // wave-uniform
@@ -564,6 +572,41 @@ extern "C" int casmtr_linear_split_prep(const float* w, void* prep, int N, int K
     return 0;
 }
 
+// the persistent producer / consumer kernel (linear_pc.hip): problems grouped by activation tensor; y1 / y2: the pooled levels (quad mode)
+static int linear_pc_dispatch(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
+                              float* const* y1, float* const* y2, int y1_tokens, int nprob, int M, int N, int K, int B, int h, int w_,
+                              hipStream_t s) {
+    Lin16pArgs a{};
+    a.M = M; a.N = N; a.h = h; a.w = w_; a.y1_tokens = y1_tokens;
+    if (w_) {
+        a.nbx = (w_ + 7) / 8; a.nby = (h + 7) / 8;
+        a.nsub = B * a.nbx * a.nby;
+    } else a.nsub = (M + 63) / 64;
+    int ng = 0, np = 0;
+    bool used[LIN_MAXP] = {false, false, false, false};
+    for (int i = 0; i < nprob; ++i) {
+        if (used[i]) continue;
+        a.x[ng] = x[i]; a.first[ng] = np;
+        for (int j = i; j < nprob; ++j) {
+            if (used[j] || x[j] != x[i]) continue;
+            used[j] = true;
+            a.wimg[np] = reinterpret_cast<const char*>(wprep[j]);
+            a.wfac[np] = reinterpret_cast<const float*>(a.wimg[np] + (size_t)N * K * 4);
+            a.bias[np] = bias ? bias[j] : nullptr;
+            a.y0[np] = y[j];
+            a.y1[np] = y1 ? y1[j] : nullptr;
+            a.y2[np] = y2 ? y2[j] : nullptr;
+            ++np;
+        }
+        a.count[ng] = np - a.first[ng];
+        ++ng;
+    }
+    a.ngroups = ng; a.nprob = np;
+    const char* xf = getenv("CASMTR_LIN_FLAGS");
+    a.xflags = xf ? atoi(xf) : 0;
+    return linear16p_launch(a, K, s);
+}
+
 extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
                                        int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream) {
     if (nprob <= 0 || M <= 0 || N <= 0) return 0;
@@ -575,10 +618,14 @@ extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const*
         lb.qh = h; lb.qw = w_;
     }
     hipStream_t s = (hipStream_t)stream;
-    const char* ev = getenv("CASMTR_LINEAR16");   // "tile": the first split kernel (one workgroup per 128 x 128 output tile), for A/B
+    const char* ev = getenv("CASMTR_LINEAR16");   // "tile": one workgroup per 128 x 128 output tile; "stationary": linear16s_kernel; for A/B
+    if ((K == 128 || (K == 256 && N % 256 == 0)) && nprob * N <= L16P_MAXFAC && !ev)   // (else: the stationary kernel below)
+        return linear_pc_dispatch(x, wprep, bias, y, nullptr, nullptr, 0, nprob, M, N, K, w_ ? M / (h * w_) : 0, h, w_, s);
     if ((K == 256 || K == 128) && !(ev && ev[0] == 't')) {   // activation-stationary kernel: problems grouped by activation tensor
         Lin16sBatch sb{};
         sb.qh = lb.qh; sb.qw = lb.qw; sb.magic_w = lb.magic_w;
+        const char* xf = getenv("CASMTR_LIN_FLAGS");
+        sb.xflags = xf ? atoi(xf) : 0;
         int ng = 0, np = 0;
         bool used[LIN_MAXP] = {false, false, false, false};
         for (int i = 0; i < nprob; ++i) {
@@ -609,6 +656,22 @@ extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const*
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_LINEAR, linear16_kernel, dim3(NIB * NJB, nprob), dim3(256), 0, s, lb, M, N, K, NJB);
     CASMTR_CHECK_LAUNCH();
     return 0;
+}
+
+// q / k / v projections WITH their pyramid (QuadtreeAttention.forward, src/model/modules/quadtree_attention.py:78-88): y0 quad-major as
+// casmtr_linear_split_fwd(h, w) writes it, y1 = avg_pool2d(y0, 2, 2) quad-major (or token-major with y1_tokens: the coarsest level of a
+// two-level pyramid), y2 = avg_pool2d(y1, 2, 2) token-major (what the coarsest level's kernel reads) -- the three tensors casmtr_quad_pool_fwd
+// produces from y0 in two more launches, bit for bit, without reading y0 or y1 back.  y1 / y2 nullable (arrays or entries).
+extern "C" int casmtr_linear_split_pyramid_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y0,
+                                               float* const* y1, float* const* y2, int y1_tokens, int nprob, int B, int h, int w_, int N,
+                                               int K, casmtr_stream_t stream) {
+    if (nprob <= 0 || B <= 0 || N <= 0) return 0;
+    if (nprob > LIN_MAXP || (K != 128 && K != 256) || N % LIN_BN != 0 || h < 2 || w_ < 2 || (h & 1) || (w_ & 1)) return CASMTR_ERR_UNSUPPORTED;
+    if ((K == 256 && N % 256 != 0) || nprob * N > L16P_MAXFAC) return CASMTR_ERR_UNSUPPORTED;
+    if (y2 && (!y1 || y1_tokens || (h & 3) || (w_ & 3))) return CASMTR_ERR_UNSUPPORTED;
+    if (y1 && !y1_tokens && ((h & 3) || (w_ & 3))) return CASMTR_ERR_UNSUPPORTED;
+    if ((long long)B * h * w_ > 0x7fffffffLL) return CASMTR_ERR_UNSUPPORTED;
+    return linear_pc_dispatch(x, wprep, bias, y0, y1, y2, y1_tokens, nprob, B * h * w_, N, K, B, h, w_, (hipStream_t)stream);
 }
 
 // =================================================================================================== token pyramid

@@ -87,6 +87,30 @@ def _project_qkv_quads(mod, x, target, hw, hw1):
     return q, k, v
 
 
+def _project_qkv_pyramid(mod, x, target, hw, hw1):
+    """projections + avg-pool pyramid in one launch (ops.linear_quads_pyramid_multi) -> ((q, k, v) of the coarsest level, token-major;
+    [(q, k, v) per finer level, quad-major, finest first]), or None when that kernel does not serve the module (exact GEMM requested,
+    more than three levels, shapes it does not cover)"""
+    import os
+    if ops.linear_gemm_mode(mod.proj_gemm) != "split" or mod.scale > 3 or os.environ.get("CASMTR_FUSED_PYRAMID", "1") == "0":
+        return None
+    ws = [w.detach().float() for w in (mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight)]
+    bs = [None if b is None else b.detach().float() for b in (mod.q_proj.bias, mod.k_proj.bias, mod.v_proj.bias)]
+    pp = _preps(mod, [mod.q_proj, mod.k_proj, mod.v_proj])
+    if x.shape == target.shape and tuple(hw) == tuple(hw1):
+        r = ops.linear_quads_pyramid_multi([x, target, target], ws, bs, *hw, mod.scale, preps=pp)
+        if r is None:
+            return None
+        q, k, v = r
+    else:
+        rq = ops.linear_quads_pyramid_multi([x], ws[:1], bs[:1], *hw, mod.scale, preps=pp[:1] if pp else None)
+        rk = ops.linear_quads_pyramid_multi([target, target], ws[1:], bs[1:], *hw1, mod.scale, preps=pp[1:] if pp else None)
+        if rq is None or rk is None:
+            return None
+        (q,), (k, v) = rq, rk
+    return (q[-1], k[-1], v[-1]), [(q[i], k[i], v[i]) for i in range(mod.scale - 1)]
+
+
 def _quad_route(mod):
     """Which kernels serve a block's inference forward.  "tokens" (default): token-major projections and the token-major attention
     kernels, whose softmax uses expf and a true division -- the route the chained reference-parity tests hold to 3e-3
@@ -157,15 +181,19 @@ class QuadtreeAttention(nn.Module):
                 and self.py_att.quads_ok(hw_q, hw_k)):
             # projections straight into the fine-level kernels' quad-major layout, pyramid on quad-major levels, the coarsest level
             # pooled into the token-major layout its kernel reads: no layout pass anywhere (round 5)
-            q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
-            finer = []
-            for i in range(self.scale - 1):
-                finer.append((q, k, v))
-                last = i == self.scale - 2
-                if hw_q[i] == hw_k[i]:
-                    q, k, v = ops.quad_pool_multi([q, k, v], *hw_q[i], to_tokens=last)
-                else:
-                    (q,), (k, v) = ops.quad_pool_multi([q], *hw_q[i], to_tokens=last), ops.quad_pool_multi([k, v], *hw_k[i], to_tokens=last)
+            pyr = _project_qkv_pyramid(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
+            if pyr is not None:   # split GEMM: the pyramid comes out of the projection's epilogue (one launch)
+                (q, k, v), finer = pyr
+            else:
+                q, k, v = _project_qkv_quads(self, x.contiguous().float(), target.contiguous().float(), (H, W), (H1, W1))
+                finer = []
+                for i in range(self.scale - 1):
+                    finer.append((q, k, v))
+                    last = i == self.scale - 2
+                    if hw_q[i] == hw_k[i]:
+                        q, k, v = ops.quad_pool_multi([q, k, v], *hw_q[i], to_tokens=last)
+                    else:
+                        (q,), (k, v) = ops.quad_pool_multi([q], *hw_q[i], to_tokens=last), ops.quad_pool_multi([k, v], *hw_k[i], to_tokens=last)
             msg = self.py_att.forward_quads((q, k, v), finer, hw_q, hw_k).view(B, -1, C)
             out = ops.linear(msg, self.proj.weight.detach().float(),
                              None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm,

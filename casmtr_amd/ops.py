@@ -259,6 +259,45 @@ def linear_quads_multi(xs, ws, biases, h, w, gemm=None, preps=None):
     return ys
 
 
+def linear_quads_pyramid_multi(xs, ws, biases, h, w, levels, preps=None):
+    """The q / k / v projections of QuadtreeAttention.forward together with their avg_pool2d pyramid in ONE launch
+    (casmtr_linear_split_pyramid_fwd, csrc/linear_pc.hip; split-f16 GEMM only).  x_i [B, h*w, K] token-major, w_i [N, K].
+    -> per problem a list of `levels` tensors, finest first: quad-major [B, N/32, (h/2^(l+1))*(w/2^(l+1)), 4, 32] for every level but
+    the last, the last (coarsest) one token-major [B, (h/2^l)*(w/2^l), N] -- what ops.linear_quads_multi followed by
+    ops.quad_pool_multi(.., to_tokens=last) returns, bit for bit.  levels in (1, 2, 3); None when the kernel does not cover the shape
+    (the caller runs the separate launches)."""
+    import ctypes as C
+    n = len(xs)
+    biases = [None] * n if biases is None else list(biases)
+    xs = [_chk(x, "x") for x in xs]
+    ws = [_chk(wt.reshape(wt.shape[0], -1), "w") for wt in ws]
+    bs = [_chk(b, "bias") for b in biases]
+    N, K = ws[0].shape
+    B = xs[0].shape[0]
+    if any(tuple(x.shape) != (B, h * w, K) for x in xs) or any(tuple(wt.shape) != (N, K) for wt in ws):
+        raise RuntimeError("linear_quads_pyramid_multi: x_i must be [B, h*w, K] and all problems share (N, K)")
+    need = max(2, 1 << (levels - 1))   # every level but the coarsest is stored as quads
+    if levels not in (1, 2, 3) or K not in (128, 256) or N % 128 or (K == 256 and N % 256) or n > 4 or n * N > 1024 or h % need or w % need:
+        return None
+    preps = [prepare_split_weight(wt) for wt in ws] if preps is None else list(preps)
+    if any(p is None for p in preps):
+        return None
+    dev = xs[0].device
+    emp = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    y0 = [emp(B, N // 32, (h // 2) * (w // 2), 4, 32) for _ in xs]
+    y1 = y2 = None
+    if levels == 2:
+        y1 = [emp(B, (h // 2) * (w // 2), N) for _ in xs]
+    elif levels == 3:
+        y1 = [emp(B, N // 32, (h // 4) * (w // 4), 4, 32) for _ in xs]
+        y2 = [emp(B, (h // 4) * (w // 4), N) for _ in xs]
+    arr = lambda ts: None if ts is None else C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().casmtr_linear_split_pyramid_fwd(arr(xs), arr(preps), arr(bs), arr(y0), arr(y1), arr(y2), int(levels == 2),
+                                                              n, B, h, w, N, K, _stream()), "linear_split_pyramid_fwd")
+    return [[t[i] for t in (y0, y1, y2) if t is not None] for i in range(n)]
+
+
 def quad_pool_multi(xs, h, w, to_tokens=False):
     """avg_pool2d(2, 2) on quad-major tensors [B, H, (h/2)*(w/2), 4, 32] (h x w tokens) -> the pooled level quad-major
     [B, H, (h/4)*(w/4), 4, 32], or token-major [B, (h/2)*(w/2), H*32] with to_tokens; one launch."""

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* casmtr_stream_t; /* hipStream_t */
 
-#define CASMTR_ABI_VERSION 7
+#define CASMTR_ABI_VERSION 8
 int casmtr_abi_version(void);
 /* Test hook (round 6): the kernels with a dynamic item schedule claim work from per-XCD counters that every launch leaves zeroed;
  * synchronises the device and returns the number of non-zero counter words (0 = consistent; < 0: HIP error).                     */
@@ -248,6 +248,18 @@ size_t casmtr_linear_split_prep_bytes(int N, int K);
 int casmtr_linear_split_prep(const float* w, void* prep, int N, int K, casmtr_stream_t stream);
 int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
                             int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream);
+
+/* The q / k / v projections of QuadtreeAttention.forward TOGETHER WITH their pyramid (src/model/modules/quadtree_attention.py:78-88:
+ * conv1x1, then F.avg_pool2d(kernel 2, stride 2) per further level) in one launch (csrc/linear_pc.hip, round 6): x_p [B, h*w, K]
+ * token-major -> y0_p quad-major as casmtr_linear_split_fwd(h, w_) writes it; y1_p = avg_pool2d(y0_p): quad-major
+ * [B][N/32][(h/4)*(w/4)][4][32] (h % 4 == w_ % 4 == 0), or with y1_tokens token-major [B][(h/2)*(w/2)][N] (the coarsest level of a
+ * two-level pyramid); y2_p = avg_pool2d(y1_p) token-major [B][(h/4)*(w/4)][N] (needs y1 quad-major).  y1 / y2: NULL, or arrays whose
+ * NULL entries skip that problem's level.  Values: bit for bit those of casmtr_linear_split_fwd + casmtr_quad_pool_fwd (+ ..._fwd
+ * with to_tokens) -- the pooled levels are summed in registers from the projected values in the same order -- without reading a
+ * projected level back.  K = 128 and N % 128 == 0, or K = 256 and N % 256 == 0; nprob <= 4; h, w_ even; else CASMTR_ERR_UNSUPPORTED.                        */
+int casmtr_linear_split_pyramid_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y0,
+                                    float* const* y1, float* const* y2, int y1_tokens, int nprob, int B, int h, int w_, int N, int K,
+                                    casmtr_stream_t stream);
 
 /* F.avg_pool2d(kernel_size=2, stride=2) of the pyramid loop (quadtree_attention.py:82-90) on QUAD-major tensors: src_i
  * [B][C/32][(h/2)*(w/2)][4][32] (h x w tokens) -> the pooled (h/2 x w/2) level, quad-major again ([B][C/32][(h/4)*(w/4)][4][32];

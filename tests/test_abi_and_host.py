@@ -28,7 +28,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"{n} declared in include/casmtr_hip.h but not exported"
     # and the python binding knows every one of them
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert _lib.lib().casmtr_abi_version() == 7
+    assert _lib.lib().casmtr_abi_version() == 8
     assert _lib.lib().casmtr_dual_softmax_ws_bytes(1, 10816, 10816) > 0
 
 

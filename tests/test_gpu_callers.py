@@ -246,13 +246,13 @@ def _rows(kind, g, M, K):
 
 @pytest.mark.parametrize("kind", ["randn", "scaled", "sparse"])
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (5408 + 37, 256, 256), (300, 256, 128), (128, 128, 256)])
-@pytest.mark.parametrize("kernel", ["stationary", "tile"])
+@pytest.mark.parametrize("kernel", ["persistent", "stationary", "tile"])
 def test_linear_split_error_bound(kind, M, N, K, kernel, monkeypatch):
     """|y_split - y_exact_chain| <= 2^-15 |x_m| |w_n| for every output (the budget derived in csrc/callers.hip), measured with a factor to
     spare; against float64 the split is as close as the fp32 chain itself.  Ragged M (rows beyond the last full 128-row tile), with bias."""
     from casmtr_amd import ops
-    if kernel == "tile":   # the first split kernel (one workgroup per 128 x 128 output tile); default: activation-stationary
-        monkeypatch.setenv("CASMTR_LINEAR16", "tile")
+    if kernel != "persistent":   # the first two split kernels (one workgroup per 128 x 128 output tile; activation-stationary);
+        monkeypatch.setenv("CASMTR_LINEAR16", kernel)   # default: the persistent producer / consumer kernel (csrc/linear_pc.hip)
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x, w = _rows(kind, g, M, K), _rows("randn" if kind == "sparse" else kind, g, N, K) * 0.05
     b = torch.randn((N,), generator=g)
@@ -303,6 +303,75 @@ def test_linear_split_multi_and_quads():
         m.proj.weight.mul_(2.0)
         m.proj.bias.mul_(2.0)
         assert torch.allclose(m(x, t, h, w), 2.0 * y0, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,share", [(1000, 256, 256, True), (64 * 256 * 3 + 5, 128, 128, False), (300, 256, 128, True),
+                                           (777, 384, 256, False), (63, 128, 256, True), (20000, 512, 128, True)])
+def test_linear_persistent_equals_stationary(M, N, K, share, monkeypatch):
+    """the persistent producer / consumer kernel multiplies the same products in the same order as the two earlier split kernels: bit-equal
+    results, token-major; ragged M, one or two activation tensors per launch, tail units (K = 128: 128-row units), more blocks than CUs"""
+    from casmtr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x, t = _rows("scaled", g, M, K).to(DEV), _rows("randn", g, M, K).to(DEV)
+    ws = [(0.05 * torch.randn((N, K), generator=g)).to(DEV) for _ in range(3)]
+    bs = [torch.randn((N,), generator=g).to(DEV), None, torch.randn((N,), generator=g).to(DEV)]
+    xs = [x, x, x] if share else [x, t, t]
+    got = ops.linear_multi(xs, ws, bs, gemm="split")
+    monkeypatch.setenv("CASMTR_LINEAR16", "stationary")
+    want = ops.linear_multi(xs, ws, bs, gemm="split")
+    for a, b_ in zip(got, want):
+        assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,h,w,N,K", [(2, 104, 104, 256, 256), (3, 60, 80, 256, 256), (1, 20, 12, 128, 128), (2, 208, 208, 128, 128),
+                                       (5, 8, 8, 256, 256), (2, 12, 20, 256, 128)])
+@pytest.mark.parametrize("levels", [1, 2, 3])
+def test_linear_pyramid_equals_linear_then_pool(B, h, w, N, K, levels, monkeypatch):
+    """casmtr_linear_split_pyramid_fwd: projections + avg_pool2d pyramid from one launch == the quad-major projection (earlier kernel)
+    followed by quad_pool launches, every level bit for bit; grids that are not multiples of the 8 x 8 tile (60 x 80, 20 x 12: partial
+    tiles), one image tile only, mixed bias / no bias, q from one tensor and k, v from another"""
+    from casmtr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(h * w + N + levels)
+    x, t = _rows("scaled", g, B * h * w, K).view(B, h * w, K).to(DEV), torch.randn((B, h * w, K), generator=g).to(DEV)
+    ws = [(0.05 * torch.randn((N, K), generator=g)).to(DEV) for _ in range(3)]
+    bs = [torch.randn((N,), generator=g).to(DEV), None, torch.randn((N,), generator=g).to(DEV)]
+    got = ops.linear_quads_pyramid_multi([x, t, t], ws, bs, h, w, levels)
+    assert got is not None and all(len(lv) == levels for lv in got)
+    monkeypatch.setenv("CASMTR_LINEAR16", "stationary")
+    want = ops.linear_quads_multi([x, t, t], ws, bs, h, w, gemm="split")
+    for i in range(levels):
+        for a, b_ in zip(got, want):
+            assert a[i].shape == b_.shape and torch.equal(a[i], b_), f"level {i}"
+        if i + 1 < levels:
+            want = ops.quad_pool_multi(want, h >> i, w >> i, to_tokens=(i + 1 == levels - 1))
+    monkeypatch.delenv("CASMTR_LINEAR16")
+    # the plain quad-major entry runs the same kernel without the pooled outputs
+    for a, b_ in zip(ops.linear_quads_multi([x, t, t], ws, bs, h, w, gemm="split"), got):
+        assert torch.equal(a, b_[0])
+    # shapes outside the kernel's cover (K = 256 with a 128-column remainder): None, the caller pools in separate launches
+    w384 = [(0.05 * torch.randn((384, 256), generator=g)).to(DEV)]
+    assert ops.linear_quads_pyramid_multi([torch.zeros((1, 64, 256), device=DEV)], w384, None, 8, 8, 2) is None
+
+
+def test_fused_pyramid_in_the_block(monkeypatch):
+    """QuadtreeAttention on the quad route with split projections: pyramid from the projection's epilogue == separate pooling launches"""
+    from casmtr_amd import _lib
+    from casmtr_amd.modules.quadtree_block import QuadtreeAttention, set_caller_layout
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, h, w, C = 2, 40, 56, 256
+    x, tgt = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
+    m = set_caller_layout(QuadtreeAttention(C, 8, [16, 8, 8], qkv_bias=True, scale=3).to(DEV).eval(), "quads", "split")
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CASMTR_FUSED_PYRAMID", fused)
+        _lib.prof_enable(True)
+        with torch.no_grad():
+            outs.append(m(x, tgt, h, w))
+        torch.cuda.synchronize()
+        times = _lib.prof_read()
+        _lib.prof_enable(False)
+        assert (times.get("token_pool", (0, 0))[1] == 0) == (fused == "1"), times.get("token_pool")
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_blocks_with_split_projections(monkeypatch):
