@@ -21,18 +21,19 @@
 //       level-1 quad's four quads and so the 4 x 4 tokens of a level-2 token, the two pooled pyramid levels come out of three adds and a
 //       multiply per value in registers, in torch's order (((c0 + c1) + c2) + c3) * 0.25 = quad_pool_kernel's: bit-identical to
 //       projecting and pooling in three launches, without reading a projected level back (0.83 ms per step of the callers leg).
-// Barriers (all eight waves, raw s_barrier -- no vmcnt drain): per block A (operand buffer free) / B (filled), per job X (out tile free) /
-// Y (filled).  Rows of a block in quad mode are the 8 x 8 tokens of one image tile in Z-order: local row = 32 ty + 16 tx + 8 qy + 4 qx +
-// 2 cy + cx for token (4 ty + 2 qy + cy, 4 tx + 2 qx + cx) of the tile.
+// Hand-offs: four monotonic counters in LDS (operand buffer free / filled per block, out tile filled / free per job), not s_barrier -- see
+// pc_signal / pc_wait below; the multiply waves run up to one job ahead of the stores.  Rows of a block in quad mode are the 8 x 8 tokens
+// of one image tile in Z-order: local row = 32 ty + 16 tx + 8 qy + 4 qx + 2 cy + cx for token (4 ty + 2 qy + cy, 4 tx + 2 qx + cx).
 //
-// Measured (profiles/r06_lin_time.txt; the same box, us per launch: this kernel / linear16s_kernel / copy of the bytes): q,k,v 335 / 338 /
-// 133; with the pyramid 314 against 338 + 118 + 26 for projection + two pooling launches; merge projection 132 / 138 / 66; cascade
-// q | k,v 255 / 272 / 165; cascade merge 104 / 97 / 67.  Without stores 229, without row loads 249, with neither 203: the parts still add
-// up more than they hide each other.  Two findings on the way: (1) tools/probes/mfma16_rate.hip -- with every SIMD issuing
-// v_mfma_f32_32x32x16_f16 on random operands the chip holds 1.3-1.55 GHz (32 cycles per MFMA at every accumulator count; one CU alone:
-// 1.95 GHz), so the three products of the q,k,v launch are 134 us of matrix pipe, as long as its bytes take; (2) a run-time `if` around
-// a load inside the k-loop, or a conditionally loaded register (bias), makes the compiler's wait-count insertion fall back to
-// vmcnt(0) / vmcnt(1) right behind the load: experiment switches live outside the hot loop only, the bias is read unconditionally.
+// Measured (profiles/r06_lin_time.txt; one box, us per launch: this kernel / linear16s_kernel / a copy of the bytes): q,k,v 323 / 350 /
+// 127; with the pyramid 302 against 350 + 117 + 26 for projection + two pooling launches; merge projection 115 / 139 / 67; cascade
+// q | k,v 225 / 274 / 160; cascade merge 86 / 98 / 67.  (With s_barrier hand-offs: 335 / 132 / 255 / 104.)  Without stores 239, without
+// row loads 254, with neither 218: the multiply waves' own pace -- 62 % of the matrix pipe at the clock it really runs at -- is what is
+// left.  Two findings on the way: (1) tools/probes/mfma16_rate.hip -- with every SIMD issuing v_mfma_f32_32x32x16_f16 on random operands
+// the chip holds 1.3-1.55 GHz (32 cycles per MFMA at every accumulator count; one CU alone: 1.95 GHz), so the three products of the q,k,v
+// launch are 134 us of matrix pipe, as long as its bytes take; (2) a run-time `if` around a load inside the k-loop, or a conditionally
+// loaded register (bias), makes the compiler's wait-count insertion fall back to vmcnt(0) / vmcnt(1) right behind the load: experiment
+// switches live outside the hot loop only, and the column factors / biases come from LDS.
 #include <stdio.h>
 #include <stdlib.h>
 #include "common.hpp"
@@ -45,9 +46,18 @@ namespace {
 
 typedef _Float16 l16_h8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void pc_barrier() {   // LDS traffic of this wave complete, then the workgroup barrier; vector-memory operations stay in flight
+// Hand-offs between the two kinds of waves go through four monotonic counters in LDS instead of s_barrier: a barrier makes every wave wait
+// for the slowest one at every job, so a helper whose stores are queued behind a busy memory system held the matrix pipe up twice per job.
+// With counters a wave waits only for the event it needs (a tile read, a tile written, the operand buffer free / filled), and the multiply
+// waves run up to one job ahead of the stores.  signal: this wave's LDS traffic is complete (lgkmcnt(0): LDS instructions of a wave complete
+// in order), then one lane adds 1; wait: spin on the counter with s_sleep.
+__device__ __forceinline__ void pc_signal(int* c) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pc_wait(const int* c, int target) {
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(c)) < target) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
 
@@ -65,6 +75,11 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
     float* facA = reinterpret_cast<float*>(As + KS * CHUNK);   // [2 parities][RB]
     float* Ot = facA + 2 * RB;                                  // out tile [RB][TW]
     float* facW = Ot + RB * TW;                                 // [nprob][N] 2^e_n, then [nprob][N] bias (0 where a problem has none)
+    int* cnt = reinterpret_cast<int*>(facW + 2 * L16P_MAXFAC);  // cA, cB, cW, cR (16 bytes apart)
+    int* cA = cnt;        // + 1 per multiply wave that has read the last stage of a block   (operand buffer free)
+    int* cB = cnt + 4;    // + 1 per helper wave that has written its share of a block        (operand buffer filled)
+    int* cW = cnt + 8;    // + 1 per multiply wave that has written its strip of an out tile (tile filled)
+    int* cR = cnt + 12;   // + 1 per helper wave that has read its share of an out tile       (tile free)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NU = (a.nsub + RT - 1) / RT, total = a.ngroups * NU;
@@ -81,6 +96,7 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
         facW[i] = a.wfac[pq][c];
         facW[a.nprob * a.N + i] = a.bias[pq] ? a.bias[pq][c] : 0.f;
     }
+    if (tid < 16) cnt[tid] = 0;
     __syncthreads();
 
     if (wave >= 4) {
@@ -149,22 +165,42 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                 }
             }
         };
-        auto drain = [&](int u, int j) {   // job j's out tile -> memory
+        // job j's out tile -> registers (tile_read), registers -> memory (tile_store; the tile may be overwritten in between)
+        f32x4 tv[16];
+        auto tile_read = [&](int u) {
+            const int ub = u - (u / NU) * NU;
+            if constexpr (!QUADS) {
+                constexpr int C4 = TW / 4;
+#pragma unroll
+                for (int k = 0; k < RB * C4 / 256; ++k) {
+                    const int c = ht + 256 * k;
+                    tv[k] = *reinterpret_cast<const f32x4*>(Ot + (c / C4) * TW + (c % C4) * 4);
+                }
+            } else {
+                // lane <-> (level-2 token of the block, head, 16-byte piece of the head's 32 channels): RT * TW combinations
+                const int c = ht, piece = c & 7, hl = (c >> 3) % HT, t2u = c / (8 * HT);
+                const int ty = (t2u >> 1) & 1, tx = t2u & 1;
+                if (c < RT * TW && ub * RT + (t2u >> 2) < a.nsub) {
+                    const float* src = Ot + ((t2u >> 2) * 64 + ty * 32 + tx * 16) * TW + hl * 32 + piece * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = *reinterpret_cast<const f32x4*>(src + r * TW);   // r = 4 t1 + c0
+                }
+            }
+        };
+        auto tile_store = [&](int u, int j) {
             if (a.xflags & 1) return;
             const int g = u / NU, ub = u - g * NU;
             const int pi = j / ncg, cg = j - pi * ncg, pp = a.first[g] + pi;
             if constexpr (!QUADS) {
-                constexpr int C4 = TW / 4, PER = RB * C4 / 256;
+                constexpr int C4 = TW / 4;
                 float* __restrict__ Y = a.y0[pp] + (size_t)cg * TW;
-#pragma unroll 8
-                for (int k = 0; k < PER; ++k) {
+#pragma unroll
+                for (int k = 0; k < RB * C4 / 256; ++k) {
                     const int c = ht + 256 * k, col4 = c % C4, row = c / C4;
                     const int gr = (ub * RT + row / 64) * 64 + (row & 63);
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(Ot + row * TW + col4 * 4);
-                    if (gr < a.M) *reinterpret_cast<f32x4*>(Y + (size_t)gr * a.N + col4 * 4) = v;
+                    if (gr < a.M) *reinterpret_cast<f32x4*>(Y + (size_t)gr * a.N + col4 * 4) = tv[k];
                 }
             } else {
-                // lane <-> (level-2 token of the block, head, 16-byte piece of the head's 32 channels): RT * TW combinations
                 const int wq = a.w >> 1, Lq = (a.h >> 1) * wq, Hh = a.N >> 5;
                 const int c = ht, piece = c & 7, hl = (c >> 3) % HT, t2u = c / (8 * HT);
                 const int sb = ub * RT + (t2u >> 2), ty = (t2u >> 1) & 1, tx = t2u & 1;
@@ -172,7 +208,6 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                 const int img = sb / nb, rem = sb - img * nb, by = rem / a.nbx, bx = rem - by * a.nbx;
                 const int head = cg * HT + hl;
                 const int T2Y = by * 2 + ty, T2X = bx * 2 + tx;
-                const float* src = Ot + ((t2u >> 2) * 64 + ty * 32 + tx * 16) * TW + hl * 32 + piece * 4;
                 float* y0h = a.y0[pp] + ((size_t)img * Hh + head) * Lq * 128 + piece * 4;
                 f32x4 p1[4];
                 bool ok0 = false;
@@ -181,9 +216,7 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                     const int QY = 2 * T2Y + (t1 >> 1), QX = 2 * T2X + (t1 & 1);
                     const bool ok = 2 * QY < a.h && 2 * QX < a.w;
                     if (t1 == 0) ok0 = ok;
-                    f32x4 v[4];
-#pragma unroll
-                    for (int c0 = 0; c0 < 4; ++c0) v[c0] = *reinterpret_cast<const f32x4*>(src + (t1 * 4 + c0) * TW);
+                    const f32x4 (&v)[4] = reinterpret_cast<const f32x4 (&)[4]>(tv[t1 * 4]);
                     if (ok) {
                         float* d = y0h + (size_t)(QY * wq + QX) * 128;
 #pragma unroll
@@ -207,11 +240,19 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                 }
             }
         };
+        int tiles = 0;   // out tiles taken so far
+        auto drain = [&](int u, int j) {
+            pc_wait(cW, 4 * (tiles + 1));   // the four strips of the tile are written
+            tile_read(u);
+            pc_signal(cR);                  // ... and read: the multiply waves may write the next one
+            ++tiles;
+            tile_store(u, j);
+        };
         issue(unit_of(0));
         convert();
         for (int it = 0; it < nit; ++it) {
             const int u = unit_of(it), nj = njobs(u);
-            pc_barrier();   // A: the multiply waves have read the last stage of the previous block
+            pc_wait(cA, 4 * it);   // the multiply waves have read the last stage of the previous block
 #pragma unroll
             for (int n = 0; n < RT; ++n) {
 #pragma unroll
@@ -222,26 +263,15 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                 }
                 if (p == 0) facA[(it & 1) * RB + n * 64 + prow] = fexp[n];
             }
-            pc_barrier();   // B: block `it` is in the buffer
-            if (it + 1 == nit) {   // (its own exit, so that the split registers are dead while raw rows are in flight)
-                for (int j = 0; j < nj; ++j) {
-                    pc_barrier();   // X
-                    pc_barrier();   // Y
-                    drain(u, j);
-                }
-                break;
-            }
-            if (!(a.xflags & 4)) issue(unit_of(it + 1));
-            for (int j = 0; j + 1 < nj; ++j) {
-                pc_barrier();   // X
-                pc_barrier();   // Y: job j's tile is in Ot
-                drain(u, j);
-            }
-            convert();      // (the loads have had the block's first jobs to arrive)
-            pc_barrier();   // X
-            pc_barrier();   // Y of the last job
-            drain(u, nj - 1);
+            pc_signal(cB);         // block `it` is in the buffer
+            // the previous block's last tile: taken only now, so that the buffer was refilled while the multiply waves wrote that tile
+            if (it > 0) { const int up = unit_of(it - 1); drain(up, njobs(up) - 1); }
+            const bool more = it + 1 < nit;
+            if (more && !(a.xflags & 4)) issue(unit_of(it + 1));
+            for (int j = 0; j + 1 < nj; ++j) drain(u, j);
+            if (more) convert();   // (the loads have had the block's first jobs to arrive)
         }
+        { const int ul = unit_of(nit - 1); drain(ul, njobs(ul) - 1); }
         return;
     }
 
@@ -265,10 +295,10 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
     loadw(q, wh[0], wl[0]);
     loadw(q + 8192, wh[1], wl[1]);
     loadw(q + 2 * 8192, wh[2], wl[2]);
+    int tiles = 0;   // out tiles written so far
     for (int it = 0; it < nit; ++it) {
         const int u = unit_of(it), g = u / NU, nj = njobs(u);
-        pc_barrier();   // A
-        pc_barrier();   // B
+        pc_wait(cB, 4 * (it + 1));   // block `it` is in the operand buffer
         for (int j = 0; j < nj; ++j) {
             const int pi = j / ncg, cg = j - pi * ncg, pp = a.first[g] + pi, col0 = cg * TW + wave * CW;
             const bool has_bias = a.bias[pp] != nullptr;
@@ -321,7 +351,8 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                 }
             }
             q = qn;
-            // y = acc * 2^e_m * 2^e_n (+ bias) -> out tile (the helpers have read job j - 1's tile: X)
+            if (j + 1 == nj) pc_signal(cA);   // this wave has read the block's last stage: the helpers may refill the buffer
+            // y = acc * 2^e_m * 2^e_n (+ bias) -> out tile, once the helpers have taken the previous one
             const float* fa_par = facA + (it & 1) * RB;
             float fbv[NT], bj[NT];
 #pragma unroll
@@ -329,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                 fbv[tj] = facW[pp * a.N + col0 + tj * 32 + ln];
                 bj[tj] = facW[(a.nprob + pp) * a.N + col0 + tj * 32 + ln];
             }
-            pc_barrier();   // X
+            pc_wait(cR, 4 * tiles);
 #pragma unroll
             for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
@@ -345,7 +376,8 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                         }
                     }
                 }
-            pc_barrier();   // Y
+            pc_signal(cW);
+            ++tiles;
         }
     }
 }
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
 template <int K, int RT, int NT, bool QUADS>
 int launch_pc(const Lin16pArgs& a, hipStream_t s) {
     constexpr int KS = K / 32, RB = 64 * RT, PLANE = 2 * RB * 16 + 32;
-    constexpr size_t lds = (size_t)KS * 4 * PLANE + 2 * RB * 4 + (size_t)RB * 128 * NT * 4 + 2 * L16P_MAXFAC * 4;
+    constexpr size_t lds = (size_t)KS * 4 * PLANE + 2 * RB * 4 + (size_t)RB * 128 * NT * 4 + 2 * L16P_MAXFAC * 4 + 64;
     static int cache[CASMTR_MAX_DEVICES];
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear16p_kernel<K, RT, NT, QUADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 0;
