@@ -324,7 +324,7 @@ def test_linear_persistent_equals_stationary(M, N, K, share, monkeypatch):
 
 
 @pytest.mark.parametrize("B,h,w,N,K", [(2, 104, 104, 256, 256), (3, 60, 80, 256, 256), (1, 20, 12, 128, 128), (2, 208, 208, 128, 128),
-                                       (5, 8, 8, 256, 256), (2, 12, 20, 256, 128)])
+                                       (5, 8, 8, 256, 256), (2, 12, 20, 256, 128), (3, 4, 4, 128, 128), (1, 4, 12, 256, 256)])
 @pytest.mark.parametrize("levels", [1, 2, 3])
 def test_linear_pyramid_equals_linear_then_pool(B, h, w, N, K, levels, monkeypatch):
     """casmtr_linear_split_pyramid_fwd: projections + avg_pool2d pyramid from one launch == the quad-major projection (earlier kernel)
