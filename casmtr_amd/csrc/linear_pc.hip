@@ -301,7 +301,6 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
         pc_wait(cB, 4 * (it + 1));   // block `it` is in the operand buffer
         for (int j = 0; j < nj; ++j) {
             const int pi = j / ncg, cg = j - pi * ncg, pp = a.first[g] + pi, col0 = cg * TW + wave * CW;
-            const bool has_bias = a.bias[pp] != nullptr;
             // the job after this one (its first three stages are prefetched under this job's last three)
             const char* qn = q;
             if (j + 1 < nj) qn = wptr(u, j + 1);
@@ -338,7 +337,9 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
                     for (int tj = 0; tj < NT; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ti], h[tj], acc[ti][tj], 0, 0, 0);
             };
             loada(0, ah[0], al[0]);
-            // (No run-time switches in this loop: a conditional load makes the compiler wait for every weight fragment right behind its load.)
+            // No run-time switches in this loop (a conditional load makes the compiler wait for every weight fragment right behind its load),
+            // and no peeled first group either (starting from a literal-zero accumulator would save 64 v_mov per job, but in straight-line
+            // code the scheduler sinks the prefetch loads down to their uses: vmcnt(0) again).
 #pragma unroll 1
             for (int s0 = 0; s0 < S2; s0 += 4) {
 #pragma unroll
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void linear16p_kernel(const Lin16pArgs a) {
 #pragma unroll
                         for (int tj = 0; tj < NT; ++tj) {
                             const float v = (acc[ti][tj][4 * rq + c0] * fa4[c0]) * fbv[tj];
-                            Ot[row * TW + wave * CW + tj * 32 + ln] = has_bias ? v + bj[tj] : v;
+                            Ot[row * TW + wave * CW + tj * 32 + ln] = v + bj[tj];   // bj = 0 without a bias: v is never -0 (exact zeros are +0)
                         }
                     }
                 }

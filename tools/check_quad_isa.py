@@ -7,6 +7,10 @@ only sound if the compiler
 fine_quad.hip additionally promises that its loop contains NO compiler-visible vector load and no compiler-generated `vmcnt` wait
 (its front end stages the next item by DMA; an ordinary load would make the compiler drain the DMA ring with its own vmcnt(0)).
 coarse_tile.hip: the instances used by the shipped configs (EMAX <= 11) must not spill; its query loads are waited for in the prologue.
+linear_pc.hip (no DMA; the compiler counts its waits): its multiply waves prefetch weight fragments three k-stages ahead, which only works
+while the compiler keeps COUNTING -- a conditional load or a conditionally defined register in or around the k-loop makes it fall back to
+`s_waitcnt vmcnt(0)` right behind every load (seen twice while the kernel was written).  Checked: no spills, and between the first and
+the last MFMA of every instance no vmcnt wait below 4.
 Compiles the files to gfx950 assembly and checks every template instance.  Exit status 0 = ok."""
 import os
 import re
@@ -113,9 +117,33 @@ def check(asm_text, kernel, n_expected):
     return problems
 
 
+def check_prefetch(asm_text, kernel, n_expected, min_in_flight):
+    problems = []
+    names = sorted(set(re.findall(rf"^(_ZN?\w*{kernel}\w+):", asm_text, re.M)))
+    if len(names) != n_expected:
+        return [f"{kernel}: expected {n_expected} instances, found {len(names)}"]
+    for name in names:
+        lines = asm_text.split(name + ":", 1)[1].split(".Lfunc_end", 1)[0].split("\n")
+        if any(re.match(r"\s*scratch_", l) for l in lines):
+            problems.append(f"{name}: scratch instructions present (register spills)")
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        if not mf:
+            problems.append(f"{name}: no MFMA found")
+            continue
+        for l in lines[mf[0]:mf[-1] + 1]:
+            m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l.split(";")[0])
+            if m and int(m.group(1)) < min_in_flight:
+                problems.append(f"{name}: {l.strip()} inside the k-loop (the weight prefetch is being drained)")
+    return problems
+
+
 def main():
     bad = []
     with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(ROOT, "casmtr_amd", "csrc", "linear_pc.hip"), os.path.join(td, "linear_pc.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+        bad += check_prefetch(open(out).read(), "linear16p_kernel", 6, 4)
         for f, kernels in FILES.items():
             src = os.path.join(ROOT, "casmtr_amd", "csrc", f)
             out = os.path.join(td, f + ".s")
