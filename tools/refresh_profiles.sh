@@ -17,6 +17,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pr
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_2c -- python $R/bench.py --config 2c --steps 5 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_callers -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --with-callers > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch_callers -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --with-callers > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write_callers -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --with-callers > /dev/null 2>&1
 find $O -name "*kernel_stats.csv" -newer $O/${TAG}_bench.json | head
 find $O -name "*counter_collection.csv" -newer $O/${TAG}_bench.json | head
 head -c 600 $O/${TAG}_bench.json
