@@ -583,7 +583,7 @@ static int linear_pc_dispatch(const float* const* x, const void* const* wprep, c
         a.nsub = B * a.nbx * a.nby;
     } else a.nsub = (M + 63) / 64;
     int ng = 0, np = 0;
-    bool used[LIN_MAXP] = {false, false, false, false};
+    bool used[L16P_MAXP] = {};
     for (int i = 0; i < nprob; ++i) {
         if (used[i]) continue;
         a.x[ng] = x[i]; a.first[ng] = np;
@@ -610,7 +610,7 @@ static int linear_pc_dispatch(const float* const* x, const void* const* wprep, c
 extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y,
                                        int nprob, int M, int N, int K, int h, int w_, casmtr_stream_t stream) {
     if (nprob <= 0 || M <= 0 || N <= 0) return 0;
-    if (nprob > LIN_MAXP || K <= 0 || K % LIN_BK != 0 || K > 256 || N % LIN_BN != 0) return CASMTR_ERR_UNSUPPORTED;
+    if (nprob > L16P_MAXP || K <= 0 || K % LIN_BK != 0 || K > 256 || N % LIN_BN != 0) return CASMTR_ERR_UNSUPPORTED;
     Linear16Batch lb{};
     if (w_) {
         if (h <= 0 || w_ <= 1 || (h & 1) || (w_ & 1) || M % (h * w_) != 0) return CASMTR_ERR_UNSUPPORTED;
@@ -621,6 +621,7 @@ extern "C" int casmtr_linear_split_fwd(const float* const* x, const void* const*
     const char* ev = getenv("CASMTR_LINEAR16");   // "tile": one workgroup per 128 x 128 output tile; "stationary": linear16s_kernel; for A/B
     if ((K == 128 || (K == 256 && N % 256 == 0)) && nprob * N <= L16P_MAXFAC && !ev)   // (else: the stationary kernel below)
         return linear_pc_dispatch(x, wprep, bias, y, nullptr, nullptr, 0, nprob, M, N, K, w_ ? M / (h * w_) : 0, h, w_, s);
+    if (nprob > LIN_MAXP) return CASMTR_ERR_UNSUPPORTED;   // the earlier kernels take four problems
     if ((K == 256 || K == 128) && !(ev && ev[0] == 't')) {   // activation-stationary kernel: problems grouped by activation tensor
         Lin16sBatch sb{};
         sb.qh = lb.qh; sb.qw = lb.qw; sb.magic_w = lb.magic_w;
@@ -666,7 +667,7 @@ extern "C" int casmtr_linear_split_pyramid_fwd(const float* const* x, const void
                                                float* const* y1, float* const* y2, int y1_tokens, int nprob, int B, int h, int w_, int N,
                                                int K, casmtr_stream_t stream) {
     if (nprob <= 0 || B <= 0 || N <= 0) return 0;
-    if (nprob > LIN_MAXP || (K != 128 && K != 256) || N % LIN_BN != 0 || h < 2 || w_ < 2 || (h & 1) || (w_ & 1)) return CASMTR_ERR_UNSUPPORTED;
+    if (nprob > L16P_MAXP || (K != 128 && K != 256) || N % LIN_BN != 0 || h < 2 || w_ < 2 || (h & 1) || (w_ & 1)) return CASMTR_ERR_UNSUPPORTED;
     if ((K == 256 && N % 256 != 0) || nprob * N > L16P_MAXFAC) return CASMTR_ERR_UNSUPPORTED;
     if (y2 && (!y1 || y1_tokens || (h & 3) || (w_ & 3))) return CASMTR_ERR_UNSUPPORTED;
     if (y1 && !y1_tokens && ((h & 3) || (w_ & 3))) return CASMTR_ERR_UNSUPPORTED;

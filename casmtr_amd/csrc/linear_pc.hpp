@@ -2,8 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define L16P_MAXP 4
-#define L16P_MAXFAC 1024   // column factors + biases of all problems live in LDS: nprob * N <= this
+#define L16P_MAXP 8          // problems per launch (the q / k / v projections of both directions of a layer: 6)
+#define L16P_MAXFAC 2048   // column factors + biases of all problems live in LDS: nprob * N <= this
 
 struct Lin16pArgs {
     const float* x[L16P_MAXP];                  // distinct activation tensors ("groups"); group g serves problems first[g] .. + count[g]

@@ -217,6 +217,46 @@ class QuadtreeAttention(nn.Module):
                              prep=(_preps(self, [self.proj]) or [None])[0])
         return self.proj_drop(out)
 
+    def forward_multi(self, calls, H, W):
+        """calls: [(x, target)] of identical shapes whose results do not depend on each other -- the two directions of a transformer layer
+        (transformer.py:295-300) -> [self.forward(x, target, H, W) for x, target in calls], from ONE projection launch (q / k / v of
+        every call written into doubled-batch quad-major operands, pyramid included), one attention launch per level and one merge
+        projection: the paired launches of QTAttB.forward_multi for callers that enter through the block.  Falls back to per-call
+        forwards where the quad route / the fused projection does not apply."""
+        n = len(calls)
+        x0, t0 = calls[0]
+        B, N, C = x0.shape
+        hw = [(H >> i, W >> i) for i in range(self.scale)]
+        ok = (n > 1 and self.attn_type == "B" and not self.py_att.lepe and self.scale in (2, 3) and x0.is_cuda and _quad_route(self)
+              and ops.linear_gemm_mode(self.proj_gemm) == "split" and 3 * n <= 8 and C % 32 == 0
+              and all(tuple(x.shape) == (B, N, C) and tuple(t.shape) == (B, N, C) for x, t in calls)
+              and all(h % 2 == 0 and w % 2 == 0 for h, w in hw[:-1]) and self.py_att.quads_ok(hw, hw)
+              and not _needs_autograd(*[t for c in calls for t in c], *self.parameters()))
+        if not ok:
+            return [self.forward(x, t, H, W) for x, t in calls]
+        lins = [self.q_proj, self.k_proj, self.v_proj]
+        ws = [l.weight.detach().float() for l in lins]
+        bs = [None if l.bias is None else l.bias.detach().float() for l in lins]
+        pp = _preps(self, lins)
+        emp = lambda *shape: torch.empty(shape, device=x0.device, dtype=torch.float32)
+        Hh = C // 32
+        big = []   # per level: (q, k, v) on the doubled batch; finest first; the coarsest token-major
+        for l in range(self.scale):
+            h, w = hw[l]
+            shape = (n * B, h * w, C) if l == self.scale - 1 else (n * B, Hh, (h // 2) * (w // 2), 4, 32)
+            big.append([emp(*shape) for _ in range(3)])
+        xs, outs = [], []
+        for g, (x, t) in enumerate(calls):
+            xc, tc = x.contiguous().float(), t.contiguous().float()
+            xs += [xc, tc, tc]
+            outs += [[big[l][j][g * B:(g + 1) * B] for l in range(self.scale)] for j in range(3)]
+        if ops.linear_quads_pyramid_multi(xs, ws * n, bs * n, H, W, self.scale, preps=None if pp is None else list(pp) * n, outs=outs) is None:
+            return [self.forward(x, t, H, W) for x, t in calls]
+        msg = self.py_att.forward_quads(tuple(big[-1]), [tuple(lv) for lv in big[:-1]], hw, hw).view(n * B, -1, C)
+        out = ops.linear(msg, self.proj.weight.detach().float(), None if self.proj.bias is None else self.proj.bias.detach().float(),
+                         gemm=self.proj_gemm, prep=(_preps(self, [self.proj]) or [None])[0])
+        return [self.proj_drop(out[g * B:(g + 1) * B]) for g in range(n)]
+
     def _forward_reference_structure(self, x, target, H, W, H1, W1, rel_pos, topk_pos):
         B, N, C = x.shape
         x = x.permute(0, 2, 1).reshape(B, C, H, W).contiguous()

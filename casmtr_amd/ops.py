@@ -259,13 +259,15 @@ def linear_quads_multi(xs, ws, biases, h, w, gemm=None, preps=None):
     return ys
 
 
-def linear_quads_pyramid_multi(xs, ws, biases, h, w, levels, preps=None):
+def linear_quads_pyramid_multi(xs, ws, biases, h, w, levels, preps=None, outs=None):
     """The q / k / v projections of QuadtreeAttention.forward together with their avg_pool2d pyramid in ONE launch
-    (casmtr_linear_split_pyramid_fwd, csrc/linear_pc.hip; split-f16 GEMM only).  x_i [B, h*w, K] token-major, w_i [N, K].
+    (casmtr_linear_split_pyramid_fwd, csrc/linear_pc.hip; split-f16 GEMM only).  x_i [B, h*w, K] token-major, w_i [N, K], up to 8
+    problems (both directions of a layer).
     -> per problem a list of `levels` tensors, finest first: quad-major [B, N/32, (h/2^(l+1))*(w/2^(l+1)), 4, 32] for every level but
-    the last, the last (coarsest) one token-major [B, (h/2^l)*(w/2^l), N] -- what ops.linear_quads_multi followed by
-    ops.quad_pool_multi(.., to_tokens=last) returns, bit for bit.  levels in (1, 2, 3); None when the kernel does not cover the shape
-    (the caller runs the separate launches)."""
+    the last, the last (coarsest) one token-major [B, (h/2^l)*(w/2^l), N] (levels == 1: the quad-major projection alone) -- what
+    ops.linear_quads_multi followed by ops.quad_pool_multi(.., to_tokens=last) returns, bit for bit.  outs: the same structure
+    preallocated by the caller (e.g. slices of doubled-batch operands); levels in (1, 2, 3); None when the kernel does not cover the
+    shape (the caller runs the separate launches)."""
     import ctypes as C
     n = len(xs)
     biases = [None] * n if biases is None else list(biases)
@@ -277,25 +279,28 @@ def linear_quads_pyramid_multi(xs, ws, biases, h, w, levels, preps=None):
     if any(tuple(x.shape) != (B, h * w, K) for x in xs) or any(tuple(wt.shape) != (N, K) for wt in ws):
         raise RuntimeError("linear_quads_pyramid_multi: x_i must be [B, h*w, K] and all problems share (N, K)")
     need = max(2, 1 << (levels - 1))   # every level but the coarsest is stored as quads
-    if levels not in (1, 2, 3) or K not in (128, 256) or N % 128 or (K == 256 and N % 256) or n > 4 or n * N > 1024 or h % need or w % need:
+    if (levels not in (1, 2, 3) or K not in (128, 256) or N % 128 or (K == 256 and N % 256) or n > 8 or n * N > 2048 or h % need or w % need):
         return None
     preps = [prepare_split_weight(wt) for wt in ws] if preps is None else list(preps)
     if any(p is None for p in preps):
         return None
     dev = xs[0].device
-    emp = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
-    y0 = [emp(B, N // 32, (h // 2) * (w // 2), 4, 32) for _ in xs]
-    y1 = y2 = None
+    shapes = [(B, N // 32, (h // 2) * (w // 2), 4, 32)]
     if levels == 2:
-        y1 = [emp(B, (h // 2) * (w // 2), N) for _ in xs]
+        shapes.append((B, (h // 2) * (w // 2), N))
     elif levels == 3:
-        y1 = [emp(B, N // 32, (h // 4) * (w // 4), 4, 32) for _ in xs]
-        y2 = [emp(B, (h // 4) * (w // 4), N) for _ in xs]
-    arr = lambda ts: None if ts is None else C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+        shapes += [(B, N // 32, (h // 4) * (w // 4), 4, 32), (B, (h // 4) * (w // 4), N)]
+    if outs is None:
+        outs = [[torch.empty(sh, device=dev, dtype=torch.float32) for sh in shapes] for _ in xs]
+    elif (len(outs) != n or any(len(o) != levels for o in outs)
+          or any(tuple(t.shape) != sh or not t.is_contiguous() or t.dtype != torch.float32 or t.device != dev for o in outs for t, sh in zip(o, shapes))):
+        raise RuntimeError("linear_quads_pyramid_multi: outs must hold contiguous fp32 tensors of the level shapes")
+    arr = lambda ts: C.cast((C.c_void_p * n)(*[_ptr(t) for t in ts]), C.c_void_p)
+    lvl = lambda l: arr([o[l] for o in outs]) if l < levels else None
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().casmtr_linear_split_pyramid_fwd(arr(xs), arr(preps), arr(bs), arr(y0), arr(y1), arr(y2), int(levels == 2),
+        _lib.check(_lib.lib().casmtr_linear_split_pyramid_fwd(arr(xs), arr(preps), arr(bs), lvl(0), lvl(1), lvl(2), int(levels == 2),
                                                               n, B, h, w, N, K, _stream()), "linear_split_pyramid_fwd")
-    return [[t[i] for t in (y0, y1, y2) if t is not None] for i in range(n)]
+    return [list(o) for o in outs]
 
 
 def quad_pool_multi(xs, h, w, to_tokens=False):

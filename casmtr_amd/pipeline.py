@@ -256,6 +256,9 @@ class HotPath(torch.nn.Module):
                 msgs += self.qta.forward_multi([(inp[f"cq{a}"][li], inp[f"ck{b}"][li], inp[f"cv{b}"][li]) for a, b in pairs],
                                                split_fine=cfg.paired_layers == "coarse")
                 continue
+            if cfg.callers and cfg.paired_layers:   # the block's own paired form: one projection launch, doubled-batch attention, one merge
+                msgs += self.coarse_blocks[layer].forward_multi([(inp[f"cx{a}"], inp[f"cx{b}"]) for a, b in pairs], h8, w8)
+                continue
             for a, b in pairs:
                 if cfg.callers:
                     msgs.append(self.coarse_blocks[layer](inp[f"cx{a}"], inp[f"cx{b}"], h8, w8))

@@ -256,7 +256,7 @@ int casmtr_linear_split_fwd(const float* const* x, const void* const* wprep, con
  * two-level pyramid); y2_p = avg_pool2d(y1_p) token-major [B][(h/4)*(w/4)][N] (needs y1 quad-major).  y1 / y2: NULL, or arrays whose
  * NULL entries skip that problem's level.  Values: bit for bit those of casmtr_linear_split_fwd + casmtr_quad_pool_fwd (+ ..._fwd
  * with to_tokens) -- the pooled levels are summed in registers from the projected values in the same order -- without reading a
- * projected level back.  K = 128 and N % 128 == 0, or K = 256 and N % 256 == 0; nprob <= 4; h, w_ even; else CASMTR_ERR_UNSUPPORTED.                        */
+ * projected level back.  K = 128 and N % 128 == 0, or K = 256 and N % 256 == 0; nprob <= 8, nprob * N <= 2048; h, w_ even; else CASMTR_ERR_UNSUPPORTED.                        */
 int casmtr_linear_split_pyramid_fwd(const float* const* x, const void* const* wprep, const float* const* bias, float* const* y0,
                                     float* const* y1, float* const* y2, int y1_tokens, int nprob, int B, int h, int w_, int N, int K,
                                     casmtr_stream_t stream);

@@ -374,6 +374,30 @@ def test_fused_pyramid_in_the_block(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_block_forward_multi_equals_per_call_forwards():
+    """QuadtreeAttention.forward_multi (both directions of a layer: six projections + their pyramids from one launch into doubled-batch
+    operands, attention and merge on the doubled batch) == one forward per direction, 'self' and 'cross' layers; and the fall-back"""
+    from casmtr_amd import _lib
+    from casmtr_amd.modules.quadtree_block import QuadtreeAttention, set_caller_layout
+    g = torch.Generator(device="cpu").manual_seed(23)
+    B, h, w, C = 2, 24, 40, 256
+    x0, x1 = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
+    m = set_caller_layout(QuadtreeAttention(C, 8, [16, 8, 8], qkv_bias=True, scale=3).to(DEV).eval(), "quads", "split")
+    with torch.no_grad():
+        for calls in ([(x0, x0), (x1, x1)], [(x0, x1), (x1, x0)]):
+            _lib.prof_enable(True)
+            got = m.forward_multi(calls, h, w)
+            torch.cuda.synchronize()
+            times = _lib.prof_read()
+            _lib.prof_enable(False)
+            assert times["linear_nt"][1] == 2 and "token_pool" not in times, times   # one projection launch + one merge
+            for a, (x, t) in zip(got, calls):
+                assert torch.equal(a, m(x, t, h, w))
+        set_caller_layout(m, "tokens", "split")   # not the quad route: per-call forwards
+        for a, (x, t) in zip(m.forward_multi([(x0, x1), (x1, x0)], h, w), [(x0, x1), (x1, x0)]):
+            assert torch.equal(a, m(x, t, h, w))
+
+
 def test_blocks_with_split_projections(monkeypatch):
     """QuadtreeAttention / CascadeQuadtreeAttention with proj_gemm='split' (what pipeline.HotPath(callers) and model.timing opt into)
     against the exact-chain projections on both routes; the split kernels ran (spy)"""

@@ -24,7 +24,7 @@ BENCH_NAME = [("fine_quad_kernel<1", "qta_fine_level[lists<=64]"), ("fine_quad_k
               ("ds_split_kernel", "dual_softmax_split_prepass"), ("ds_rownorm_kernel", "dual_softmax_split_prepass"), ("ds_fix_kernel", "dual_softmax_fix"),
               ("nchw_to_tokens_kernel", "layout[token-major]"), ("coarse_row_kernel", "coarse_row_kernel"),
               ("coarse_logits_kernel", "coarse_logits_kernel"), ("coarse_av_kernel", "coarse_av_kernel"),
-              ("linear_nt_kernel", "linear_nt"), ("linear16_kernel", "linear_nt"), ("token_pool_kernel", "token_pool"), ("quad_pool_kernel", "token_pool")]
+              ("linear_nt_kernel", "linear_nt"), ("linear16_kernel", "linear_nt"), ("linear16s_kernel", "linear_nt"), ("linear16p_kernel", "linear_nt"), ("token_pool_kernel", "token_pool"), ("quad_pool_kernel", "token_pool")]
 
 
 def per_kernel(path, counter):
