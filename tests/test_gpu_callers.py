@@ -374,6 +374,17 @@ def test_fused_pyramid_in_the_block(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_linear_persistent_stress():
+    """random shapes / problem counts / sharing patterns / grids through the persistent kernel's LDS-counter hand-offs, bit for bit
+    against the stationary kernel and the pooling launches (tools/lin_stress.py)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lin_stress.py"), "120", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "120 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_block_forward_multi_equals_per_call_forwards():
     """QuadtreeAttention.forward_multi (both directions of a layer: six projections + their pyramids from one launch into doubled-batch
     operands, attention and merge on the doubled batch) == one forward per direction, 'self' and 'cross' layers; and the fall-back"""
