@@ -42,7 +42,7 @@ for name, run, nbytes in cases:
     b = torch.empty_like(a)
     cp = timed(lambda: b.copy_(a))
     out = [f"{name}: {nbytes / 1e6:.0f} MB moved; copy of as many bytes {cp:.1f} us"]
-    for fl in ("0", "1", "4", "5"):
+    for fl in ("0", "0", "1", "4", "5"):   # (the first column still carries the allocator's first-use cost of the output shapes)
         os.environ["CASMTR_LIN_FLAGS"] = fl
         out.append(f"persistent kernel, flags {fl}: {timed(run):.1f} us")
     os.environ["CASMTR_LINEAR16"] = "stationary"
