@@ -448,6 +448,8 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
     // fragment (ti, part): plane (kg = hi, part), row wr*64 + ti*32 + ln
     const char* fa_base = lds + (hi * 2) * 2048 + (wr * 64 + ln) * 16;
     const char* fb_base = lds + 8192 + (hi * 2) * 2048 + (wc * 64 + ln) * 16;
+    if (store & 2) __builtin_amdgcn_s_setprio(2);   // waves in the k-loop ahead of waves in an epilogue (default; CASMTR_DS_PRIO=0 / 2: off / the other way round):
+                                                    // 1.574-1.582 against 1.592-1.611 ms, alternating on one box (tools/ds_prio.py)
     int buf = 0;
     for (int ks = 0; ks < KS; ++ks) {
         // stage ks has landed when only stage ks + 1 (4 instructions) is still in flight.  No __syncthreads here: its
@@ -475,6 +477,11 @@ __global__ __launch_bounds__(256, 3) void ds_gemm16_kernel(const _Float16* __res
         buf = buf == 2 ? 0 : buf + 1;
     }
     __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's scratch
+    if (store & 2) __builtin_amdgcn_s_setprio(0);
+    if (store & 4) __builtin_amdgcn_s_setprio(2);   // experiment (CASMTR_DS_PRIO=2): the other way round
+    const int prio_bits = store & 6;
+    store &= 1;
+    (void)prio_bits;
     if (tI * DS_BM + DS_BM <= L && tJ * DS_BN + DS_BN <= S) {
         if (store) {
             if (any_masked) ds_split_epilogue<true, true>(acc, smem, facA, facB, sim, w, b, tI, tJ, L, S, NJB, NIB);
@@ -502,8 +509,10 @@ int ds_gemm16_launch(const uint8_t* mask0, const uint8_t* mask1, float* sim, con
     const size_t lds = DS16_LDS3;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ds_gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     prof_symbol_args(CASMTR_PROF_DS_GEMM, "%s", store ? " (similarity matrix stored)" : " (statistics only: no matrix store)");
+    const char* pe = getenv("CASMTR_DS_PRIO");
+    const int prio = pe ? (atoi(pe) & 3) * 2 : 2;
     CASMTR_LAUNCH_TIMED(CASMTR_PROF_DS_GEMM, ds_gemm16_kernel, dim3(ntiles, B), dim3(256), lds, s, w.imgA, w.imgB, w.fa, w.fb,
-                        mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, store);
+                        mask0, mask1, sim, w, L, S, C / 16, NJB, NIB, (store ? 1 : 0) | prio);
     CASMTR_CHECK_LAUNCH();
     return 0;
 }
