@@ -294,6 +294,38 @@ class CascadeQuadtreeAttention(nn.Module):
         self.proj_gemm = None   # "exact" | "split" | None (= ops.linear_gemm_mode default): see set_caller_layout
         self.apply(_init_weights)
 
+    def forward_multi(self, calls, H, W):
+        """calls: [(x, target, idx)] of identical shapes, independent of each other (the two directions of a cascade cross layer,
+        transformer.py:549), no rel_pos, no index output -> [self.forward(x, target, H, W, idx=idx, want_idx=False)[0] for ...] from one
+        projection launch into doubled-batch quad-major operands, one attention launch and one merge projection."""
+        n = len(calls)
+        x0, t0, i0 = calls[0]
+        B, N, C = x0.shape
+        ok = (n > 1 and 3 * n <= 8 and x0.is_cuda and _quad_route(self) and ops.linear_gemm_mode(self.proj_gemm) == "split" and C % 32 == 0
+              and H % 2 == 0 and W % 2 == 0 and self.cross_attn.quads_ok((H, W), (H, W), i0.shape[2])
+              and all(tuple(x.shape) == (B, N, C) and tuple(t.shape) == (B, N, C) and tuple(ix.shape) == tuple(i0.shape) for x, t, ix in calls)
+              and not _needs_autograd(*[t for c in calls for t in c[:2]], *self.parameters()))
+        if not ok:
+            return [self.forward(x, t, H, W, idx=ix, want_idx=False)[0] for x, t, ix in calls]
+        lins = [self.q_proj, self.k_proj, self.v_proj]
+        ws = [l.weight.detach().float() for l in lins]
+        bs = [None if l.bias is None else l.bias.detach().float() for l in lins]
+        pp = _preps(self, lins)
+        big = [torch.empty((n * B, C // 32, (H // 2) * (W // 2), 4, 32), device=x0.device, dtype=torch.float32) for _ in range(3)]
+        xs, outs = [], []
+        for g, (x, t, _) in enumerate(calls):
+            xc, tc = x.contiguous().float(), t.contiguous().float()
+            xs += [xc, tc, tc]
+            outs += [[big[j][g * B:(g + 1) * B]] for j in range(3)]
+        if ops.linear_quads_pyramid_multi(xs, ws * n, bs * n, H, W, 1, preps=None if pp is None else list(pp) * n, outs=outs) is None:
+            return [self.forward(x, t, H, W, idx=ix, want_idx=False)[0] for x, t, ix in calls]
+        tp = torch.cat([ix.contiguous() for _, _, ix in calls], 0)
+        msg = self.cross_attn.forward_quads(big[0], big[1], big[2], (H, W), (H, W), tp, None)
+        out = ops.linear(msg.view(n * B, -1, C), self.proj.weight.detach().float(),
+                         None if self.proj.bias is None else self.proj.bias.detach().float(), gemm=self.proj_gemm,
+                         prep=(_preps(self, [self.proj]) or [None])[0])
+        return [self.proj_drop(out[g * B:(g + 1) * B]) for g in range(n)]
+
     def forward(self, x, target, H, W, H1=None, W1=None, idx=None, rel_pos=None, want_idx=True):
         """x [B,H*W,C], target [B,H1*W1,C], idx [B,(H/2)(W/2),KW,2] -> (x' [B,H*W,C], upsampled_idx [B,H*W,4KW])
         (src/model/modules/quadtree_attention.py:152-176).  want_idx=False: see CascadeQTAttB.forward."""

@@ -409,6 +409,21 @@ def test_block_forward_multi_equals_per_call_forwards():
             assert torch.equal(a, m(x, t, h, w))
 
 
+def test_cascade_block_forward_multi_equals_per_call_forwards():
+    from casmtr_amd import ops
+    from casmtr_amd.modules.quadtree_block import CascadeQuadtreeAttention, set_caller_layout
+    g = torch.Generator(device="cpu").manual_seed(29)
+    B, hq, C = 2, 14, 128
+    h = w = 2 * hq
+    x0, x1 = torch.randn((B, h * w, C), generator=g).to(DEV), torch.randn((B, h * w, C), generator=g).to(DEV)
+    tp = [ops.window_warp_idx(torch.randint(0, hq * hq, (B, hq * hq), generator=g).to(DEV), hq, hq, 5) for _ in range(2)]
+    c = set_caller_layout(CascadeQuadtreeAttention(C, 4, qkv_bias=True).to(DEV).eval(), "quads", "split")
+    with torch.no_grad():
+        calls = [(x0, x1, tp[0]), (x1, x0, tp[1])]
+        for a, (x, t, ix) in zip(c.forward_multi(calls, h, w), calls):
+            assert torch.equal(a, c(x, t, h, w, idx=ix, want_idx=False)[0])
+
+
 def test_blocks_with_split_projections(monkeypatch):
     """QuadtreeAttention / CascadeQuadtreeAttention with proj_gemm='split' (what pipeline.HotPath(callers) and model.timing opt into)
     against the exact-chain projections on both routes; the split kernels ran (spy)"""
